@@ -1,0 +1,538 @@
+/*
+ * wdx_oracle.c -- CPU restatement of the WarpDemuX sig_proc / parallel_distances hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the shipped engine (warpdemux_amd/) never does.
+ *
+ * Parity status
+ *   stage A (fingerprint chain, A0-A6): PINNED -- checked bit-for-bit against outputs of the
+ *     reference's own warpdemux.sig_proc / _c_segmentation imported in the build container
+ *     (tests/golden/make_golden.py -> tests/golden/ fixtures; NumPy 2.2.6 / SciPy 1.15.3).
+ *   stage B (banded DTW): PARITY UNPINNED -- the arithmetic lives in dtaidistance==2.3.13
+ *     (environment.yml:13), which is neither vendored in the reference tree nor installable
+ *     here.  This file restates the published dtw_distance recurrence and is
+ *     anchored on the library's documented example, a literal full-matrix restatement and a
+ *     property suite (tests/test_oracle_dtw.py).
+ *
+ * Every function cites the reference lines it follows (paths relative to /root/reference).
+ * All double arithmetic must be compiled WITHOUT fused-multiply-add contraction
+ * (-ffp-contract=off) so that it reproduces the x86-64 baseline build of the Cython module.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define WDX_OK 0
+#define WDX_FAIL_DETECT 1   /* detect_results.success == False, sig_proc.py:400-407           */
+#define WDX_FAIL_SIGNORM 2  /* "signal normalization failed: ...", sig_proc.py:433-446        */
+#define WDX_FAIL_SEGMENT 3  /* "event segmentation failed", sig_proc.py:537-544               */
+#define WDX_FAIL_SEGNORM 4  /* "segment normalization failed: ...", sig_proc.py:546-560       */
+#define WDX_FAIL_UNKNOWN 5  /* exception escaping to barcode_fpt_wrapper, file_proc.py:220-224 */
+
+typedef struct {
+    int32_t padding;            /* sig_extract.padding (config/sig_proc.py:18)                 */
+    int32_t sig_norm;           /* sig_extract.normalization: 0 none, 1 mean, 2 median         */
+    float outlier_thresh;       /* core.sig_norm_outlier_thresh                                */
+    int32_t min_obs_per_base;   /* segmentation.min_obs_per_base                               */
+    int32_t running_stat_width; /* segmentation.running_stat_width                             */
+    int32_t num_events;         /* segmentation.num_events                                     */
+    int32_t accept_less_cpts;   /* segmentation.accept_less_cpts                               */
+    int32_t seg_norm;           /* segmentation.normalization: 0 none, 1 mean, 2 median        */
+    int32_t barcode_num_events; /* segmentation.barcode_num_events (int form)                  */
+} wdx_seg_params;
+
+/* ------------------------------------------------------------------------------------------ */
+/* small selection / sorting helpers                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+static void nth_f32(float *a, int64_t n, int64_t k) {
+    /* in-place quickselect: afterwards a[k] is the k-th order statistic, a[<k] <= a[k] <= a[>k] */
+    int64_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        float p = a[lo + (hi - lo) / 2];
+        int64_t i = lo, j = hi;
+        while (i <= j) {
+            while (a[i] < p) i++;
+            while (a[j] > p) j--;
+            if (i <= j) {
+                float t = a[i]; a[i] = a[j]; a[j] = t;
+                i++; j--;
+            }
+        }
+        if (k <= j) hi = j;
+        else if (k >= i) lo = i;
+        else return;
+    }
+}
+
+/* np.nanmedian of a float32 vector (numpy/lib/_nanfunctions_impl.py::_nanmedian1d ->
+ * np.median): NaNs dropped; odd n -> middle element; even n -> float32 mean of the two middle
+ * elements, i.e. fl32(fl32(a+b)/2).  Empty -> NaN.  scratch must hold n floats. */
+static float nanmedian_f32(const float *x, int64_t n, float *scratch) {
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (x[i] == x[i]) scratch[m++] = x[i];
+    if (m == 0) return NAN;
+    int64_t h = m / 2;
+    nth_f32(scratch, m, h);
+    float hi = scratch[h];
+    if (m & 1) return hi;
+    float lo = scratch[0];
+    for (int64_t i = 1; i < h; i++)
+        if (scratch[i] > lo) lo = scratch[i];
+    float s = lo + hi;
+    return s / 2.0f;
+}
+
+static int cmp_f64(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* np.median of a float64 vector without NaNs (np.median sorts NaN last and returns NaN if any;
+ * callers here guarantee none). even n -> (a+b)/2 in float64. */
+static double median_f64(const double *x, int64_t n, double *scratch) {
+    if (n == 0) return NAN;
+    memcpy(scratch, x, (size_t)n * sizeof(double));
+    qsort(scratch, (size_t)n, sizeof(double), cmp_f64);
+    if (n & 1) return scratch[n / 2];
+    return (scratch[n / 2 - 1] + scratch[n / 2]) / 2.0;
+}
+
+/* numpy pairwise summation for float64 (numpy/_core/src/umath/loops_utils.h.src::pairwise_sum),
+ * which np.mean / np.std use through add.reduce. */
+static double np_pairwise_sum(const double *a, int64_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+static double np_mean_f64(const double *a, int64_t n) { return np_pairwise_sum(a, n) / (double)n; }
+
+/* np.std(ddof=0): numpy/_core/_methods.py::_var -> sqrt */
+static double np_std_f64(const double *a, int64_t n, double *scratch) {
+    double mean = np_mean_f64(a, n);
+    for (int64_t i = 0; i < n; i++) {
+        double d = a[i] - mean;
+        scratch[i] = d * d;
+    }
+    return sqrt(np_pairwise_sum(scratch, n) / (double)n);
+}
+
+/* Python round(): float -> nearest int, ties to even (used at sig_proc.py:528,532) */
+static int64_t py_round(double v) { return (int64_t)nearbyint(v); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* A3: windowed t-statistic   (segmentation/_c_segmentation.pyx:124-161)                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* x: float64 signal of length n; scores: n - 2*w outputs. Returns number of scores or <0 when the
+ * Cython function would have raised (w == 0 -> ZeroDivisionError; n - 2w < 0 -> np.empty raises). */
+int64_t wdx_oracle_windowed_t_test(const double *x, int64_t n, int64_t w, double *scores) {
+    int64_t num_cands = n - 2 * w;
+    if (num_cands < 0) return -1;
+    if (num_cands > 0 && w == 0) return -1;
+    for (int64_t pos = 0; pos < num_cands; pos++) {
+        double m1 = 0, m2 = 0, var1 = 0, var2 = 0, d;
+        for (int64_t i = 0; i < w; i++) m1 += x[pos + i];
+        m1 /= (double)w;
+        for (int64_t i = 0; i < w; i++) m2 += x[pos + w + i];
+        m2 /= (double)w;
+        for (int64_t i = 0; i < w; i++) {
+            d = x[pos + i] - m1;
+            var1 += d * d;
+        }
+        for (int64_t i = 0; i < w; i++) {
+            d = x[pos + w + i] - m2;
+            var2 += d * d;
+        }
+        if (var1 + var2 == 0)
+            scores[pos] = 0.0;
+        else if (m1 > m2)
+            scores[pos] = (m1 - m2) / sqrt(var1 + var2);
+        else
+            scores[pos] = (m2 - m1) / sqrt(var1 + var2);
+    }
+    return num_cands;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A4: scipy.signal.find_peaks(scores, distance=d)  (call site sig_proc.py:183) */
+/* ------------------------------------------------------------------------------------------ */
+
+/* scipy/signal/_peak_finding_utils.pyx::_local_maxima_1d -- midpoints only */
+static int64_t local_maxima_1d(const double *x, int64_t n, int64_t *mid) {
+    int64_t m = 0, i = 1, i_max = n - 1;
+    while (i < i_max) {
+        if (x[i - 1] < x[i]) {
+            int64_t ia = i + 1;
+            while (ia < i_max && x[ia] == x[i]) ia++;
+            if (x[ia] < x[i]) {
+                mid[m++] = (i + ia - 1) / 2;
+                i = ia;
+            }
+        }
+        i++;
+    }
+    return m;
+}
+
+/* stable ascending argsort of key[idx[.]] (ties keep ascending index order).  The reference uses
+ * np.argsort's default (unstable) kind, so the order among exactly equal scores is unspecified
+ * there; this restatement fixes it as "stable", and the HIP path follows the same rule. */
+static void stable_argsort(const double *key, int64_t n, int64_t *order, int64_t *tmp) {
+    for (int64_t i = 0; i < n; i++) order[i] = i;
+    for (int64_t width = 1; width < n; width *= 2) {
+        for (int64_t lo = 0; lo < n; lo += 2 * width) {
+            int64_t mid = lo + width < n ? lo + width : n;
+            int64_t hi = lo + 2 * width < n ? lo + 2 * width : n;
+            int64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                if (key[order[j]] < key[order[i]]) tmp[k++] = order[j++];
+                else tmp[k++] = order[i++];
+            }
+            while (i < mid) tmp[k++] = order[i++];
+            while (j < hi) tmp[k++] = order[j++];
+        }
+        memcpy(order, tmp, (size_t)n * sizeof(int64_t));
+    }
+}
+
+/* find_peaks(x, distance): local maxima + _select_by_peak_distance (priority = height).
+ * peaks_out must hold n/2+1 entries. Returns number of kept peaks (ascending positions). */
+int64_t wdx_oracle_find_peaks(const double *x, int64_t n, int64_t distance, int64_t *peaks_out) {
+    if (n < 3) return 0;
+    int64_t cap = n / 2 + 2;
+    int64_t *peaks = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap * 3);
+    int64_t *order = peaks + cap, *tmp = order + cap;
+    double *prio = (double *)malloc(sizeof(double) * (size_t)cap);
+    unsigned char *keep = (unsigned char *)malloc((size_t)cap);
+    int64_t np_ = local_maxima_1d(x, n, peaks);
+    for (int64_t i = 0; i < np_; i++) {
+        prio[i] = x[peaks[i]];
+        keep[i] = 1;
+    }
+    stable_argsort(prio, np_, order, tmp);
+    for (int64_t i = np_ - 1; i >= 0; i--) {
+        int64_t j = order[i];
+        if (!keep[j]) continue;
+        int64_t k = j - 1;
+        while (k >= 0 && peaks[j] - peaks[k] < distance) keep[k--] = 0;
+        k = j + 1;
+        while (k < np_ && peaks[k] - peaks[j] < distance) keep[k++] = 0;
+    }
+    int64_t m = 0;
+    for (int64_t i = 0; i < np_; i++)
+        if (keep[i]) peaks_out[m++] = peaks[i];
+    free(peaks);
+    free(prio);
+    free(keep);
+    return m;
+}
+
+/* discrepenacy_curve_to_cpts  (sig_proc.py:176-198).
+ * cpts must hold num_events+2 entries.  Returns the number of boundaries written, 0 for the
+ * "return np.array([])" branch, -1 when the reference would raise (distance < 1 in find_peaks,
+ * or indexing an empty array). */
+int64_t wdx_oracle_scores_to_cpts(const double *scores, int64_t n_scores, int64_t num_events,
+                                  int64_t min_obs_per_base, int64_t running_stat_width,
+                                  int accept_less_cpts, int64_t *cpts) {
+    if (min_obs_per_base < 1) return -1; /* scipy: "`distance` must be greater or equal to 1" */
+    int64_t cap = n_scores / 2 + 2;
+    int64_t *peaks = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap * 3);
+    int64_t *order = peaks + cap, *tmp = order + cap;
+    double *h = (double *)malloc(sizeof(double) * (size_t)cap);
+    int64_t np_ = wdx_oracle_find_peaks(scores, n_scores, min_obs_per_base, peaks);
+    int64_t ret;
+    if (np_ < num_events && !accept_less_cpts) {
+        ret = 0;
+    } else if (np_ == 0) {
+        ret = -1; /* valid_cpts[0] on an empty array -> IndexError */
+    } else {
+        for (int64_t i = 0; i < np_; i++) h[i] = scores[peaks[i]];
+        stable_argsort(h, np_, order, tmp);
+        int64_t take = np_ < num_events ? np_ : num_events;
+        /* mark the `take` highest, then emit ascending by position (== valid_cpts.sort()) */
+        unsigned char *sel = (unsigned char *)calloc((size_t)np_, 1);
+        for (int64_t i = np_ - take; i < np_; i++) sel[order[i]] = 1;
+        int64_t m = 0;
+        cpts[m++] = 0; /* peaks >= 1 so valid_cpts[0] = peak + W != 0 always */
+        for (int64_t i = 0; i < np_; i++)
+            if (sel[i]) cpts[m++] = peaks[i] + running_stat_width;
+        int64_t signal_len = n_scores + 2 * running_stat_width;
+        if (cpts[m - 1] != signal_len) cpts[m++] = signal_len;
+        free(sel);
+        ret = m;
+    }
+    free(peaks);
+    free(h);
+    return ret;
+}
+
+/* A5: c_new_means (segmentation/_c_segmentation.pyx:41-53) */
+void wdx_oracle_new_means(const double *x, const int64_t *segs, int64_t n_segs, double *means) {
+    for (int64_t s = 0; s < n_segs; s++) {
+        double sum = 0;
+        for (int64_t i = segs[s]; i < segs[s + 1]; i++) sum += x[i];
+        means[s] = sum / (double)(segs[s + 1] - segs[s]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A0-A7: detect_results_to_fpt, non-refinement branch (sig_proc.py:394-605)                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One read.  row: the read's minibatch row (float32, length row_len, NaN tail allowed); it is NOT
+ * modified (the reference clips it in place, sig_proc.py:426-431, but nothing reads it again).
+ * Outputs: fpt[K], dwell[K], stats[6] = {dt_med, dt_mad, event_mean, event_std, event_med,
+ * event_mad}; optional debug outputs (may be NULL): cpts_out[num_events+2] & n_cpts_out.
+ * Returns a WDX_* status. On failure outputs are left untouched. */
+int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_start, int32_t a_end,
+                               int ok, const wdx_seg_params *p, double *fpt, int64_t *dwell,
+                               double *stats, int64_t *cpts_out, int64_t *n_cpts_out) {
+    if (n_cpts_out) *n_cpts_out = 0;
+    if (!ok) return WDX_FAIL_DETECT;
+    /* A0 extract_adapter, sig_proc.py:382-391 */
+    int64_t start = (int64_t)a_start - p->padding;
+    if (start < 0) start = 0;
+    int64_t stop = (int64_t)a_end + p->padding;
+    if (stop > row_len) stop = row_len;
+    int64_t n = stop - start;
+    if (n < 0) n = 0; /* empty python slice */
+    int status = WDX_OK;
+    float *sig = (float *)malloc(sizeof(float) * (size_t)(n + 1) * 2);
+    float *scratch = sig + n + 1;
+    double *x = (double *)malloc(sizeof(double) * (size_t)(n + 1) * 2);
+    double *scores = x + n + 1;
+    int64_t E = p->num_events;
+    int64_t *cpts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(E + 2));
+    double *ev = (double *)malloc(sizeof(double) * (size_t)(E + 2) * 4);
+    double *z = ev + (E + 2), *tmp = z + (E + 2), *tmp2 = tmp + (E + 2);
+    memcpy(sig, row + start, sizeof(float) * (size_t)n);
+
+    /* A1 MAD outlier clip, sig_proc.py:421-431 (float32 throughout under NumPy>=2 promotion) */
+    float med = nanmedian_f32(sig, n, scratch);
+    {
+        float *dev = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - med);
+        float mad = nanmedian_f32(dev, n, scratch);
+        free(dev);
+        float tm = p->outlier_thresh * mad;
+        float lo = med - tm, hi = med + tm;
+        for (int64_t i = 0; i < n; i++) {
+            /* np.clip == minimum(maximum(x, lo), hi) with NaN propagation */
+            float v = sig[i];
+            if (v != v) continue;
+            if (lo != lo || hi != hi) { sig[i] = NAN; continue; }
+            if (!(v > lo)) v = lo;
+            if (!(v < hi)) v = hi;
+            sig[i] = v;
+        }
+    }
+
+    /* A2 normalize(adapter_sig, sig_extract.normalization, accept_nan=True), sig_proc.py:114-136.
+     * size 0 -> returned as is.  "none" is the only shipped setting. */
+    if (n > 0 && p->sig_norm != 0) {
+        int has_nan = 0;
+        for (int64_t i = 0; i < n; i++) has_nan |= (sig[i] != sig[i]);
+        if (p->sig_norm == 1) {
+            /* mean_normalize on float32 (np.mean/np.std resp. nanmean/nanstd, float32 pairwise).
+             * Not restated: no shipped config uses it. */
+            status = WDX_FAIL_SIGNORM;
+            goto done;
+        } else if (p->sig_norm == 2) {
+            float shift = nanmedian_f32(sig, n, scratch);
+            float *dev = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+            for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - shift);
+            float scale = nanmedian_f32(dev, n, scratch);
+            free(dev);
+            (void)has_nan; /* nan- and plain medians agree when there is no NaN */
+            for (int64_t i = 0; i < n; i++) sig[i] = (sig[i] - shift) / scale;
+        } else {
+            status = WDX_FAIL_SIGNORM; /* "Normalization method ... not recognized." */
+            goto done;
+        }
+    }
+
+    {
+        /* parameter shrink, sig_proc.py:526-533 */
+        if (E <= 0) { status = WDX_FAIL_UNKNOWN; goto done; } /* ZeroDivisionError */
+        int64_t d = py_round((double)n / (double)E / 2.0);
+        if (p->min_obs_per_base < d) d = p->min_obs_per_base;
+        int64_t w = py_round((double)n / (double)E);
+        if (p->running_stat_width < w) w = p->running_stat_width;
+
+        /* A3 windowed_t_test, segmentation.py:32-45 (exception -> zeros(0)) */
+        for (int64_t i = 0; i < n; i++) x[i] = (double)sig[i];
+        int64_t ns = wdx_oracle_windowed_t_test(x, n, w, scores);
+        if (ns < 0) ns = 0;
+
+        /* A4 */
+        int64_t nc = wdx_oracle_scores_to_cpts(scores, ns, E, d, w, p->accept_less_cpts, cpts);
+        if (nc < 0) { status = WDX_FAIL_UNKNOWN; goto done; }
+        if (nc == 0) { status = WDX_FAIL_SEGMENT; goto done; }
+        if (cpts_out) memcpy(cpts_out, cpts, sizeof(int64_t) * (size_t)nc);
+        if (n_cpts_out) *n_cpts_out = nc;
+
+        /* A5 compute_base_means, segmentation.py:48-74; dwell sig_proc.py:251 */
+        int64_t nseg = nc - 1;
+        wdx_oracle_new_means(x, cpts, nseg, ev);
+        if (nseg == 0) { status = WDX_FAIL_SEGMENT; goto done; } /* segment_avgs.size == 0 */
+
+        /* A6 normalize(segment_avgs, segmentation.normalization, accept_nan=False) */
+        int has_nan = 0;
+        for (int64_t i = 0; i < nseg; i++) has_nan |= (ev[i] != ev[i]);
+        if (has_nan) { status = WDX_FAIL_SEGNORM; goto done; }
+        if (p->seg_norm == 1) {
+            double mean = np_mean_f64(ev, nseg);
+            double sd = np_std_f64(ev, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) z[i] = (ev[i] - mean) / sd;
+        } else if (p->seg_norm == 2) {
+            double m = median_f64(ev, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(ev[i] - m);
+            double s = median_f64(tmp2, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) z[i] = (ev[i] - m) / s;
+        } else if (p->seg_norm == 0) {
+            for (int64_t i = 0; i < nseg; i++) z[i] = ev[i];
+        } else {
+            status = WDX_FAIL_SEGNORM;
+            goto done;
+        }
+
+        /* stats, sig_proc.py:562-567 */
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = (double)(cpts[i + 1] - cpts[i]);
+        double dt_med = median_f64(tmp2, nseg, tmp);
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(tmp2[i] - dt_med);
+        double dt_mad = median_f64(tmp2, nseg, tmp);
+        double ev_mean = np_mean_f64(ev, nseg);
+        double ev_std = np_std_f64(ev, nseg, tmp);
+        double ev_med = median_f64(ev, nseg, tmp);
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(ev[i] - ev_med);
+        double ev_mad = median_f64(tmp2, nseg, tmp);
+
+        /* tail, sig_proc.py:569-594.  Fewer than K segments: np.pad of the int64 dwell vector with
+         * NaN raises -> "unknown" via barcode_fpt_wrapper. */
+        int64_t K = p->barcode_num_events;
+        if (nseg < K) { status = WDX_FAIL_UNKNOWN; goto done; }
+        for (int64_t i = 0; i < K; i++) {
+            fpt[i] = z[nseg - K + i];
+            dwell[i] = cpts[nseg - K + i + 1] - cpts[nseg - K + i];
+        }
+        stats[0] = dt_med; stats[1] = dt_mad; stats[2] = ev_mean;
+        stats[3] = ev_std; stats[4] = ev_med; stats[5] = ev_mad;
+    }
+done:
+    free(sig);
+    free(x);
+    free(cpts);
+    free(ev);
+    return status;
+}
+
+/* batch driver mirroring the per-read loop at file_proc.py:418-428 */
+int wdx_oracle_fingerprint_batch(const float *sig, int64_t n_reads, int64_t stride,
+                                 const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                                 const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
+                                 int32_t *status) {
+    int64_t K = p->barcode_num_events;
+    for (int64_t r = 0; r < n_reads; r++) {
+        status[r] = wdx_oracle_fingerprint_one(sig + r * stride, stride, a_start[r], a_end[r],
+                                               ok ? ok[r] : 1, p, fpt + r * K, dwell + r * K,
+                                               stats + r * 6, NULL, NULL);
+    }
+    return 0;
+}
+
+/* packed-segment form used by the bench: read r occupies sig[off[r] .. off[r+1]) */
+int wdx_oracle_fingerprint_packed(const float *sig, const int64_t *off, int64_t n_reads,
+                                  const int32_t *a_start, const int32_t *a_end,
+                                  const wdx_seg_params *p, double *fpt, int64_t *dwell,
+                                  double *stats, int32_t *status) {
+    int64_t K = p->barcode_num_events;
+    for (int64_t r = 0; r < n_reads; r++) {
+        status[r] = wdx_oracle_fingerprint_one(sig + off[r], off[r + 1] - off[r], a_start[r],
+                                               a_end[r], 1, p, fpt + r * K, dwell + r * K,
+                                               stats + r * 6, NULL, NULL);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* B1: banded DTW, dtaidistance 2.3.x dtw_distance semantics (call sites     */
+/*     parallel_distances.py:34-43, 59-67).  PARITY UNPINNED, see header.                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* distance between s1[l1] and s2[l2]; window<=0 -> unbanded; penalty is squared internally.
+ * Two rolling rows, +inf outside the band, sqrt at the end. */
+double wdx_oracle_dtw_distance(const double *s1, int64_t l1, const double *s2, int64_t l2,
+                               int64_t window, double penalty) {
+    int64_t w = window > 0 ? window : (l1 > l2 ? l1 : l2);
+    double p2 = penalty * penalty;
+    int64_t dl12 = l1 > l2 ? l1 - l2 : 0, dl21 = l2 > l1 ? l2 - l1 : 0;
+    double *prev = (double *)malloc(sizeof(double) * (size_t)(l2 + 1) * 2);
+    double *cur = prev + (l2 + 1);
+    for (int64_t j = 0; j <= l2; j++) prev[j] = INFINITY;
+    prev[0] = 0.0;
+    for (int64_t i = 0; i < l1; i++) {
+        for (int64_t j = 0; j <= l2; j++) cur[j] = INFINITY;
+        int64_t j0 = i - dl12 - (w - 1);
+        if (j0 < 0) j0 = 0;
+        int64_t j1 = i + w + dl21;
+        if (j1 > l2) j1 = l2;
+        for (int64_t j = j0; j < j1; j++) {
+            double d = (s1[i] - s2[j]) * (s1[i] - s2[j]);
+            double minv = prev[j];
+            double t = prev[j + 1] + p2;
+            if (t < minv) minv = t;
+            t = cur[j] + p2;
+            if (t < minv) minv = t;
+            cur[j + 1] = d + minv;
+        }
+        double *sw = prev; prev = cur; cur = sw;
+    }
+    double r = sqrt(prev[l2]);
+    free(prev < cur ? prev : cur);
+    return r;
+}
+
+/* distance_matrix_to(X, Y, window, penalty, n_jobs=1) -> float32 (nX, nY)
+ * (parallel_distances.py:48-67: dtw_distance(read, ref) for every pair, cast to float32) */
+int wdx_oracle_dtw_matrix(const double *X, int64_t nX, const double *Y, int64_t nY, int64_t L,
+                          int64_t window, double penalty, float *out) {
+    for (int64_t r = 0; r < nX; r++)
+        for (int64_t c = 0; c < nY; c++)
+            out[r * nY + c] = (float)wdx_oracle_dtw_distance(X + r * L, L, Y + c * L, L, window, penalty);
+    return 0;
+}
+
+/* B3: nearest-reference call: np.argmin over the float32 row (first minimum; NaN wins first) */
+void wdx_oracle_argmin_rows(const float *D, int64_t nX, int64_t nY, int32_t *call) {
+    for (int64_t r = 0; r < nX; r++) {
+        const float *row = D + r * nY;
+        int32_t best = 0;
+        float bv = row[0];
+        if (bv == bv) {
+            for (int64_t c = 1; c < nY; c++) {
+                if (row[c] != row[c]) { best = (int32_t)c; break; }
+                if (row[c] < bv) { bv = row[c]; best = (int32_t)c; }
+            }
+        }
+        call[r] = best;
+    }
+}

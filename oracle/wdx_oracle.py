@@ -1,0 +1,203 @@
+"""ctypes front-end of oracle/libwdx_oracle.so -- TEST INFRASTRUCTURE ONLY (see wdx_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libwdx_oracle.so")
+
+NORM_CODES = {"none": 0, "mean": 1, "median": 2}
+FAIL_REASONS = {
+    0: "",
+    1: "detect failed",
+    2: "signal normalization failed",
+    3: "event segmentation failed",
+    4: "segment normalization failed",
+    5: "unknown",
+}
+
+
+class SegParamsC(C.Structure):
+    _fields_ = [
+        ("padding", C.c_int32),
+        ("sig_norm", C.c_int32),
+        ("outlier_thresh", C.c_float),
+        ("min_obs_per_base", C.c_int32),
+        ("running_stat_width", C.c_int32),
+        ("num_events", C.c_int32),
+        ("accept_less_cpts", C.c_int32),
+        ("seg_norm", C.c_int32),
+        ("barcode_num_events", C.c_int32),
+    ]
+
+
+@dataclass
+class SegParams:
+    """Values of config_files/rna004_130bps@v1.0.toml; outlier_thresh = ADAPTed default 5.0."""
+
+    padding: int = 100
+    sig_norm: str = "none"
+    outlier_thresh: float = 5.0
+    min_obs_per_base: int = 6
+    running_stat_width: int = 12
+    num_events: int = 110
+    accept_less_cpts: bool = False
+    seg_norm: str = "mean"
+    barcode_num_events: int = 25
+
+    def to_c(self) -> SegParamsC:
+        return SegParamsC(
+            self.padding, NORM_CODES[self.sig_norm], self.outlier_thresh, self.min_obs_per_base,
+            self.running_stat_width, self.num_events, int(self.accept_less_cpts),
+            NORM_CODES[self.seg_norm], self.barcode_num_events,
+        )
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "wdx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libwdx_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        P = C.POINTER
+        L.wdx_oracle_windowed_t_test.restype = C.c_int64
+        L.wdx_oracle_windowed_t_test.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.wdx_oracle_find_peaks.restype = C.c_int64
+        L.wdx_oracle_find_peaks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.wdx_oracle_scores_to_cpts.restype = C.c_int64
+        L.wdx_oracle_scores_to_cpts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        L.wdx_oracle_new_means.restype = None
+        L.wdx_oracle_new_means.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.wdx_oracle_fingerprint_one.restype = C.c_int
+        L.wdx_oracle_fingerprint_one.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_fingerprint_batch.restype = C.c_int
+        L.wdx_oracle_fingerprint_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_fingerprint_packed.restype = C.c_int
+        L.wdx_oracle_fingerprint_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_dtw_distance.restype = C.c_double
+        L.wdx_oracle_dtw_distance.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_double]
+        L.wdx_oracle_dtw_matrix.restype = C.c_int
+        L.wdx_oracle_dtw_matrix.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p]
+        L.wdx_oracle_argmin_rows.restype = None
+        L.wdx_oracle_argmin_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def windowed_t_test(x: np.ndarray, w: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(max(x.size - 2 * w, 0), dtype=np.float64)
+    n = lib().wdx_oracle_windowed_t_test(_p(x), x.size, w, _p(out))
+    return out[: max(n, 0)]
+
+
+def find_peaks(x: np.ndarray, distance: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty(x.size // 2 + 2, dtype=np.int64)
+    n = lib().wdx_oracle_find_peaks(_p(x), x.size, distance, _p(out))
+    return out[:n]
+
+
+def scores_to_cpts(scores, num_events=110, min_obs_per_base=6, running_stat_width=12, accept_less_cpts=False):
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    out = np.empty(num_events + 2, dtype=np.int64)
+    n = lib().wdx_oracle_scores_to_cpts(_p(scores), scores.size, num_events, min_obs_per_base, running_stat_width, int(accept_less_cpts), _p(out))
+    if n < 0:
+        raise ValueError("reference would raise")
+    return out[:n]
+
+
+def new_means(x, segs) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    segs = np.ascontiguousarray(segs, dtype=np.int64)
+    out = np.empty(segs.size - 1, dtype=np.float64)
+    lib().wdx_oracle_new_means(_p(x), _p(segs), segs.size - 1, _p(out))
+    return out
+
+
+def fingerprint_one(row, a_start, a_end, params: SegParams, ok=True):
+    """-> dict(status, fpt, dwell, stats, cpts)"""
+    row = np.ascontiguousarray(row, dtype=np.float32)
+    K = params.barcode_num_events
+    fpt = np.full(K, np.nan)
+    dwell = np.zeros(K, dtype=np.int64)
+    stats = np.full(6, np.nan)
+    cpts = np.zeros(params.num_events + 2, dtype=np.int64)
+    ncp = C.c_int64(0)
+    pc = params.to_c()
+    st = lib().wdx_oracle_fingerprint_one(_p(row), row.size, int(a_start), int(a_end), int(ok), C.byref(pc), _p(fpt), _p(dwell), _p(stats), _p(cpts), C.byref(ncp))
+    return dict(status=st, fpt=fpt, dwell=dwell, stats=stats, cpts=cpts[: ncp.value])
+
+
+def fingerprint_batch(sig, a_start, a_end, params: SegParams, ok=None):
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    n, stride = sig.shape
+    K = params.barcode_num_events
+    a_start = np.ascontiguousarray(a_start, dtype=np.int32)
+    a_end = np.ascontiguousarray(a_end, dtype=np.int32)
+    okp = None if ok is None else np.ascontiguousarray(ok, dtype=np.uint8)
+    fpt = np.full((n, K), np.nan)
+    dwell = np.zeros((n, K), dtype=np.int64)
+    stats = np.full((n, 6), np.nan)
+    status = np.zeros(n, dtype=np.int32)
+    pc = params.to_c()
+    lib().wdx_oracle_fingerprint_batch(_p(sig), n, stride, _p(a_start), _p(a_end), None if okp is None else _p(okp), C.byref(pc), _p(fpt), _p(dwell), _p(stats), _p(status))
+    return fpt, dwell, stats, status
+
+
+def fingerprint_packed(sig, off, a_start, a_end, params: SegParams):
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    n = off.size - 1
+    K = params.barcode_num_events
+    a_start = np.ascontiguousarray(a_start, dtype=np.int32)
+    a_end = np.ascontiguousarray(a_end, dtype=np.int32)
+    fpt = np.full((n, K), np.nan)
+    dwell = np.zeros((n, K), dtype=np.int64)
+    stats = np.full((n, 6), np.nan)
+    status = np.zeros(n, dtype=np.int32)
+    pc = params.to_c()
+    lib().wdx_oracle_fingerprint_packed(_p(sig), _p(off), n, _p(a_start), _p(a_end), C.byref(pc), _p(fpt), _p(dwell), _p(stats), _p(status))
+    return fpt, dwell, stats, status
+
+
+def dtw_distance(a, b, window=None, penalty=None) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return lib().wdx_oracle_dtw_distance(_p(a), a.size, _p(b), b.size, int(window or 0), float(penalty or 0.0))
+
+
+def dtw_matrix(X, Y, window=None, penalty=None) -> np.ndarray:
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    Y = np.ascontiguousarray(Y, dtype=np.float64)
+    out = np.empty((X.shape[0], Y.shape[0]), dtype=np.float32)
+    lib().wdx_oracle_dtw_matrix(_p(X), X.shape[0], _p(Y), Y.shape[0], X.shape[1], int(window or 0), float(penalty or 0.0), _p(out))
+    return out
+
+
+def argmin_rows(D) -> np.ndarray:
+    D = np.ascontiguousarray(D, dtype=np.float32)
+    out = np.empty(D.shape[0], dtype=np.int32)
+    lib().wdx_oracle_argmin_rows(_p(D), D.shape[0], D.shape[1], _p(out))
+    return out

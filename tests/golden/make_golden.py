@@ -1,0 +1,308 @@
+"""Generate golden vectors by running the REFERENCE's own sig_proc / segmentation code.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference travels: the
+committed fixtures hold inputs made by this repo's generator (warpdemux_amd/synth.py) or small
+literal arrays, and the arrays the reference returned for them.
+
+Recipe: the segmentation half imports once the un-vendored dependencies
+(adapted, dtaidistance, ruptures) are replaced by stub modules exposing only the names used at
+import time; `_c_segmentation.pyx` is compiled by pyximport into ~/.pyxbld.
+
+    python tests/golden/make_golden.py        # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    @dataclass
+    class DetectResults:
+        success: bool = True
+        fail_reason: str = ""
+        adapter_start: int | None = None
+        adapter_end: int | None = None
+
+    @dataclass
+    class AdaptedReadResult:
+        read_id: str | None = None
+        success: bool = True
+        fail_reason: str = ""
+        detect_results: object = None
+
+        def to_summary_dict(self):
+            return {}
+
+    @dataclass
+    class BaseConfig:
+        pass
+
+    @dataclass
+    class SigProcConfig(BaseConfig):
+        pass
+
+    mod("adapted")
+    mod("adapted.container_types", DetectResults=DetectResults, ReadResult=AdaptedReadResult)
+    mod("adapted.config")
+    mod("adapted.config.base", BaseConfig=BaseConfig)
+    mod("adapted.config.sig_proc", SigProcConfig=SigProcConfig)
+    mod("dtaidistance")
+    mod("dtaidistance.dtw", warping_paths_fast=None)
+    mod("dtaidistance.subsequence", SubsequenceAlignment=None)
+    mod("ruptures", KernelCPD=None)
+    sys.path.insert(0, REF)
+    import warpdemux.sig_proc as sp  # noqa: E402  (compiles the .pyx via pyximport)
+    from warpdemux.segmentation.segmentation import compute_base_means, windowed_t_test
+
+    return sp, DetectResults, windowed_t_test, compute_base_means
+
+
+def make_spc(padding=100, sig_norm="none", thresh=5.0, d=6, w=12, E=110, accept_less=False, seg_norm="mean", K=25):
+    return SimpleNamespace(
+        sig_extract=SimpleNamespace(padding=padding, normalization=sig_norm),
+        core=SimpleNamespace(sig_norm_outlier_thresh=thresh),
+        segmentation=SimpleNamespace(
+            num_events=E, min_obs_per_base=d, running_stat_width=w, accept_less_cpts=accept_less,
+            consensus_refinement=False, normalization=seg_norm, barcode_num_events=K,
+        ),
+    )
+
+
+STATUS_OF = {
+    "": 0,
+    "event segmentation failed": 3,
+    "unknown": 5,
+}
+
+
+def status_code(res) -> int:
+    if res.success:
+        return 0
+    fr = res.fail_reason
+    if fr.startswith("signal normalization failed"):
+        return 2
+    if fr.startswith("segment normalization failed"):
+        return 4
+    if fr in STATUS_OF:
+        return STATUS_OF[fr]
+    return 1  # passthrough of detect failure
+
+
+def main():
+    from warpdemux_amd import synth
+
+    sp, DetectResults, windowed_t_test, compute_base_means = import_reference()
+    rng = np.random.Generator(np.random.PCG64(20250101))
+    spec = synth.SynthSpec(n_barcodes=10)
+
+    # ---------------- G1: t-scores --------------------------------------------------------------
+    g1 = {}
+    sigs = []
+    for rid in range(6):
+        s, _ = synth.generate_read(spec, rid)
+        sigs.append(s)
+    sigs.append(rng.normal(90, 12, 1500).astype(np.float32))
+    sigs.append(rng.normal(0, 1, 10000).astype(np.float32))
+    sigs.append(np.full(300, 77.25, dtype=np.float32))                     # constant: v1+v2 == 0 branch
+    sigs.append(np.repeat(rng.normal(80, 15, 40), 25).astype(np.float32))   # noise-free steps: plateaus of 0
+    sigs.append(rng.normal(90, 12, 30).astype(np.float32))
+    sigs.append(rng.normal(90, 12, 24).astype(np.float32))                  # N == 2W for W=12
+    sigs.append(rng.normal(90, 12, 25).astype(np.float32))                  # N == 2W+1
+    sigs.append((rng.integers(60, 120, 4000)).astype(np.float32))           # integer-valued: exact score ties
+    sigs.append((rng.normal(1e-3, 1e-4, 2000)).astype(np.float32))          # tiny magnitudes
+    sigs.append((rng.normal(0, 1, 2000) * np.logspace(-6, 6, 2000)).astype(np.float32))  # wide dynamic range
+    k = 0
+    for i, s in enumerate(sigs):
+        for w in (12, 18, 30):
+            if s.size - 2 * w < 0 or (1 <= i < 6 and w != 12):
+                continue
+            sc = windowed_t_test(s, running_stat_width=w)
+            g1[f"sig_{k}"] = s
+            g1[f"w_{k}"] = np.int64(w)
+            g1[f"scores_{k}"] = np.asarray(sc, dtype=np.float64)
+            k += 1
+    g1["n"] = np.int64(k)
+    np.savez_compressed(os.path.join(HERE, "g1_tscores.npz"), **g1)
+    print("G1 cases:", k)
+
+    # ---------------- G2/G3: change-points, event means, dwell ----------------------------------
+    g2 = {}
+    k = 0
+    triples = [(110, 6, 12), (110, 15, 30), (40, 6, 12), (110, 3, 6)]
+    for i, s in enumerate(sigs):
+        for (E, d, w) in triples:
+            if s.size - 2 * w <= 0:
+                continue
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ev, dw, sc = sp.segment_signal(s, num_events=E, min_obs_per_base=d, running_stat_width=w)
+            sc = windowed_t_test(s, running_stat_width=w)
+            cp = sp.discrepenacy_curve_to_cpts(sc, num_events=E, min_obs_per_base=d, running_stat_width=w)
+            g2[f"sig_{k}"] = s
+            g2[f"params_{k}"] = np.array([E, d, w], dtype=np.int64)
+            g2[f"cpts_{k}"] = np.asarray(cp, dtype=np.int64)
+            g2[f"means_{k}"] = np.asarray(ev, dtype=np.float64)
+            g2[f"dwell_{k}"] = np.asarray(dw, dtype=np.int64)
+            k += 1
+    g2["n"] = np.int64(k)
+    np.savez_compressed(os.path.join(HERE, "g2_cpts_means.npz"), **g2)
+    print("G2/G3 cases:", k)
+
+    # ---------------- G4: detect_results_to_fpt end to end --------------------------------------
+    g4 = {}
+    k = 0
+
+    def run_case(row, a_start, a_end, ok=True, tag="", **spc_kw):
+        nonlocal k
+        spc = make_spc(**spc_kw)
+        dr = DetectResults(success=ok, fail_reason="" if ok else "no adapter", adapter_start=a_start, adapter_end=a_end)
+        row_in = np.array(row, dtype=np.float32, copy=True)
+        row_work = row_in.copy()  # the reference clips its input row in place
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = sp.detect_results_to_fpt(row_work, spc, dr)
+            st = status_code(res)
+        except Exception:  # what barcode_fpt_wrapper turns into fail_reason="unknown"
+            res, st = None, 5
+        K = spc.segmentation.barcode_num_events
+        fpt = np.full(K, np.nan)
+        dwell = np.zeros(K, dtype=np.int64)
+        stats = np.full(6, np.nan)
+        if st == 0:
+            fpt[:] = res.barcode_fpt
+            dwell[:] = res.dwell_times
+            stats[:] = [res.adapter_dt_med, res.adapter_dt_mad, res.adapter_event_mean,
+                        res.adapter_event_std, res.adapter_event_med, res.adapter_event_mad]
+        g4[f"row_{k}"] = row_in
+        if tag in ("synth_K25", "heavy_flicker", "nan_tail", "nan_middle", "constant") and k < 6 or tag != "synth_K25" and tag in ("heavy_flicker", "nan_tail", "nan_middle", "constant"):
+            g4[f"clipped_{k}"] = row_work
+        g4[f"args_{k}"] = np.array([a_start, a_end, int(ok)], dtype=np.int64)
+        p = spc
+        g4[f"params_{k}"] = np.array(
+            [p.sig_extract.padding, {"none": 0, "mean": 1, "median": 2}[p.sig_extract.normalization],
+             p.segmentation.min_obs_per_base, p.segmentation.running_stat_width, p.segmentation.num_events,
+             int(p.segmentation.accept_less_cpts), {"none": 0, "mean": 1, "median": 2}[p.segmentation.normalization],
+             K], dtype=np.int64)
+        g4[f"thresh_{k}"] = np.float64(p.core.sig_norm_outlier_thresh)
+        g4[f"status_{k}"] = np.int64(st)
+        g4[f"fpt_{k}"] = fpt
+        g4[f"dwell_{k}"] = dwell
+        g4[f"stats_{k}"] = stats
+        g4[f"tag_{k}"] = np.array(tag)
+        k += 1
+        return st
+
+    stride = 10000
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 100, 24, stride)
+    for i in range(24):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_K25")
+    for i in range(8):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_K110", K=110)
+    for i in range(4):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_rna002_triple", d=15, w=30)
+    for i in range(4):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_thresh3_pad5", thresh=3.0, padding=5)
+    for i in range(4):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_segnorm_median", seg_norm="median")
+    for i in range(2):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_segnorm_none", seg_norm="none")
+    for i in range(2):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_signorm_median", sig_norm="median")
+    # detect failure passthrough
+    run_case(mb[0], 100, 4000, ok=False, tag="detect_failed")
+    # NaN-tailed row: adapter_end + padding reaches into the NaN tail
+    ln = int(a_e[1]) + 100
+    run_case(mb[1], int(a_s[1]), ln + 50, tag="nan_tail")
+    # adapter window clipped at row start / row end
+    run_case(mb[2], 40, int(a_e[2]), tag="start_clipped")
+    short = mb[3][:3000].copy()
+    run_case(short, 100, 3500, tag="end_clipped_by_row")
+    # short adapters exercising min(cfg, round(...)) shrink (sig_proc.py:526-533)
+    for n in (1320, 1210, 1100, 990, 880, 660, 500):
+        s = np.repeat(rng.normal(80, 15, n // 5 + 1), 5)[:n] + rng.normal(0, 1.0, n)
+        run_case(s.astype(np.float32), 0, n, tag=f"short_{n}", padding=0)
+    for n in (330, 221, 220, 219, 111, 110, 109, 60, 24, 3, 1, 0):
+        s = rng.normal(80, 15, max(n, 1))[:n]
+        run_case(s.astype(np.float32), 0, n, tag=f"tiny_{n}", padding=0)
+    # too few peaks -> "event segmentation failed"
+    run_case(rng.normal(90, 1, 1400).astype(np.float32), 0, 1400, tag="too_few_peaks", padding=0)
+    # constant signal: mad == 0, all scores 0
+    run_case(np.full(5000, 80.0, dtype=np.float32), 100, 4900, tag="constant")
+    # noise-free steps (many zero-variance windows)
+    run_case(np.repeat(rng.normal(80, 15, 200), 25).astype(np.float32), 100, 4900, tag="noise_free_steps")
+    # heavy flicker
+    hv = mb[4].copy()
+    idx = rng.integers(200, 4000, 60)
+    hv[idx] += rng.choice([-150.0, 150.0], 60).astype(np.float32)
+    run_case(hv, int(a_s[4]), int(a_e[4]), tag="heavy_flicker")
+    # all-NaN adapter window
+    run_case(np.full(4000, np.nan, dtype=np.float32), 100, 3900, tag="all_nan")
+    # NaN in the middle
+    nm = mb[5].copy()
+    nm[2000:2003] = np.nan
+    run_case(nm, int(a_s[5]), int(a_e[5]), tag="nan_middle")
+    # accept_less_cpts
+    run_case(rng.normal(90, 1, 1400).astype(np.float32), 0, 1400, tag="accept_less_few", padding=0, accept_less=True)
+    run_case(mb[6], int(a_s[6]), int(a_e[6]), tag="accept_less_enough", accept_less=True)
+    # E != 110
+    run_case(mb[7], int(a_s[7]), int(a_e[7]), tag="E60_K30", E=60, K=30)
+    run_case(mb[7], int(a_s[7]), int(a_e[7]), tag="E110_K111", K=111)
+    run_case(mb[7], int(a_s[7]), int(a_e[7]), tag="E110_K112", K=112)
+    g4["n"] = np.int64(k)
+    np.savez_compressed(os.path.join(HERE, "g4_fingerprint.npz"), **g4)
+    sts = [int(g4[f"status_{i}"]) for i in range(k)]
+    print("G4 cases:", k, "status histogram:", {s: sts.count(s) for s in sorted(set(sts))})
+
+    # ---------------- G5: normalize helpers ------------------------------------------------------
+    g5 = {}
+    k = 0
+    for n in (1, 2, 7, 8, 9, 111, 128, 129, 300, 1000):
+        a = rng.normal(3, 2, n)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            g5[f"a_{k}"] = a
+            g5[f"mean_{k}"] = sp.normalize(a, "mean")
+            g5[f"median_{k}"] = sp.normalize(a, "median")
+            g5[f"np_mean_{k}"] = np.float64(a.mean())
+            g5[f"np_std_{k}"] = np.float64(a.std())
+            g5[f"np_median_{k}"] = np.float64(np.median(a))
+        k += 1
+    for n in (1, 2, 3, 4, 101, 1000, 4801):
+        a = rng.normal(80, 12, n).astype(np.float32)
+        a_nan = a.copy()
+        if n > 2:
+            a_nan[rng.integers(0, n, max(1, n // 10))] = np.nan
+        g5[f"f32_{k}"] = a_nan
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            med = np.nanmedian(a_nan)
+            mad = np.nanmedian(np.abs(a_nan - med))
+        g5[f"f32_med_{k}"] = np.float32(med)
+        g5[f"f32_mad_{k}"] = np.float32(mad)
+        k += 1
+    g5["n"] = np.int64(k)
+    np.savez_compressed(os.path.join(HERE, "g5_normalize.npz"), **g5)
+    print("G5 cases:", k)
+
+
+if __name__ == "__main__":
+    main()
