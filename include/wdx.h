@@ -1,0 +1,179 @@
+/*
+ * wdx.h -- C ABI of libwdx_hip.so, the MI355X (gfx950) engine for the WarpDemuX
+ *          sig_proc / parallel_distances hot path.
+ *
+ * Plain pointers and sizes only; no torch / numpy / HIP types.  Paths below are relative to the
+ * reference tree (KleistLab/WarpDemuX v1.0.0).
+ *
+ * Two families of entry points:
+ *   - HOST-BUFFER calls  (wdx_dtw_matrix, wdx_fingerprint_batch, ...): the caller owns every
+ *     buffer (NumPy arrays); the library copies in/out and keeps nothing but the opaque context.
+ *     These are what a ctypes binding inside warpdemux.parallel_distances / warpdemux.sig_proc
+ *     would call.
+ *   - DEVICE-RESIDENT calls (*_dev): every data pointer is a HIP device pointer on the context's
+ *     device, `stream` is a hipStream_t passed as void* (NULL = default stream).  They enqueue
+ *     work and return without synchronising.  Used by the fused pipeline and by bench.py.
+ *
+ * All functions return WDX_SUCCESS (0) or a negative WDX_ERR_* code; wdx_last_error() gives the
+ * message for the calling thread.  Per-read soft failures are reported in status[] exactly like
+ * the reference's ReadResult.success / fail_reason (sig_proc.py:26-62) and never fail the call.
+ *
+ * Threading: a context may be used from several threads (entry points serialise on it); create
+ * one context per thread/stream for concurrency.  HIP is initialised lazily inside
+ * wdx_ctx_create, so a process may fork (file_proc.py:1197) before creating its context.
+ */
+#ifndef WDX_H
+#define WDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WDX_ABI_VERSION 1
+
+/* ---- call status ------------------------------------------------------------------------- */
+#define WDX_SUCCESS 0
+#define WDX_ERR_INVALID (-1)     /* bad argument (maps to ValueError in the Python shim)        */
+#define WDX_ERR_NO_DEVICE (-2)   /* no usable HIP device / runtime                              */
+#define WDX_ERR_HIP (-3)         /* a HIP call failed                                           */
+#define WDX_ERR_UNSUPPORTED (-4) /* legal in the reference, not implemented by this engine      */
+#define WDX_ERR_NO_REFS (-5)     /* a call that needs wdx_set_refs() came before it             */
+
+/* ---- per-read status (fingerprint stage); 0 == ReadResult.success ------------------------ */
+#define WDX_READ_OK 0
+#define WDX_READ_FAIL_DETECT 1  /* detect_results.success False   sig_proc.py:400-407           */
+#define WDX_READ_FAIL_SIGNORM 2 /* "signal normalization failed"  sig_proc.py:433-446           */
+#define WDX_READ_FAIL_SEGMENT 3 /* "event segmentation failed"    sig_proc.py:537-544           */
+#define WDX_READ_FAIL_SEGNORM 4 /* "segment normalization failed" sig_proc.py:546-560           */
+#define WDX_READ_FAIL_UNKNOWN 5 /* exception -> "unknown"         file_proc.py:209-224          */
+
+/* normalisation selectors (sig_proc.py:114-136) */
+#define WDX_NORM_NONE 0
+#define WDX_NORM_MEAN 1
+#define WDX_NORM_MEDIAN 2
+
+/* The hot-path knobs of SigProcConfig (config/sig_proc.py:16-70 + ADAPTed core.*), by value. */
+typedef struct wdx_seg_params {
+    int32_t padding;            /* sig_extract.padding                                          */
+    int32_t sig_norm;           /* sig_extract.normalization   (WDX_NORM_*)                     */
+    float outlier_thresh;       /* core.sig_norm_outlier_thresh                                 */
+    int32_t min_obs_per_base;   /* segmentation.min_obs_per_base                                */
+    int32_t running_stat_width; /* segmentation.running_stat_width                              */
+    int32_t num_events;         /* segmentation.num_events                                      */
+    int32_t accept_less_cpts;   /* segmentation.accept_less_cpts                                */
+    int32_t seg_norm;           /* segmentation.normalization  (WDX_NORM_*)                     */
+    int32_t barcode_num_events; /* segmentation.barcode_num_events (int form)                   */
+} wdx_seg_params;
+
+typedef struct wdx_ctx wdx_ctx;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int wdx_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). Never NULL. */
+const char *wdx_last_error(void);
+/* Number of visible HIP devices, or a negative WDX_ERR_*. Does not create a context. */
+int wdx_device_count(void);
+/* Create a context on HIP device `device`.  First HIP use in the process happens here. */
+int wdx_ctx_create(int device, wdx_ctx **out);
+void wdx_ctx_destroy(wdx_ctx *ctx);
+/* Block until all work enqueued through this context on `stream` has finished. */
+int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream);
+
+/* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,
+ *      i.e. dtaidistance.dtw.distance_matrix(vstack[X,Y], block=((0,nX),(nX,nX+nY)),
+ *      window, penalty, use_c=True)[:nX, nX:].astype(float32) ) ------------------------------ */
+
+/* X: (nX,L) float64 row-major host; Y: (nY,L) float64 row-major host; out: (nX,nY) float32 host.
+ * window <= 0 means unbanded (reference: None/0); penalty is the un-squared dtaidistance penalty
+ * (0 = none).  argmin (nullable): int32[nX] = np.argmin(out, axis=1).  Both nX and nY may be 0. */
+int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, int64_t nY,
+                   int64_t L, int32_t window, double penalty, float *out, int32_t *argmin);
+
+/* Upload the reference set once (model._X, models/dtw_base.py:14-17) and keep it resident.
+ * Y is a HOST pointer; it is re-uploaded only if its content/params differ from the cached set. */
+int wdx_set_refs(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
+                 double penalty);
+
+/* Device-resident DTW against the resident reference set.
+ * dX: (nX,L) float64 row-major DEVICE; d_out: (nX,nY) float32 DEVICE;
+ * d_argmin (nullable): int32[nX] DEVICE. */
+int wdx_dtw_matrix_dev(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out,
+                       int32_t *d_argmin, void *stream);
+
+/* ---- seam 2: batched fingerprinting (replaces the per-read loop file_proc.py:418-428 over
+ *      sig_proc.py:394-605 `detect_results_to_fpt`, non-refinement branch) ------------------- */
+
+/* sig: (n_reads, stride) float32 host minibatch, NaN tail (file_proc.py:244-260);
+ * a_start/a_end: DetectResults.adapter_start/end; ok (nullable): DetectResults.success.
+ * Outputs (host): fpt (n_reads,K) float64, dwell (n_reads,K) int64, stats (n_reads,6) float64 =
+ * {adapter_dt_med, adapter_dt_mad, adapter_event_mean, adapter_event_std, adapter_event_med,
+ * adapter_event_mad}, status int32[n_reads] (WDX_READ_*).  Rows of failed reads hold NaN / 0.
+ * K = p->barcode_num_events.  The input rows are NOT clipped in place (the reference's
+ * in-place clip, sig_proc.py:426-431, is never read again: file_proc.py:430). */
+int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                          const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                          const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
+                          int32_t *status);
+
+/* Device-resident form.  Read r occupies d_sig[row_off[r] .. row_off[r] + row_len[r]) where
+ *   d_row_off == NULL  -> row_off[r] = r*stride        (minibatch layout)
+ *   d_row_len == NULL  -> row_len[r] = d_row_off ? d_row_off[r+1]-d_row_off[r] : stride
+ * (so a packed batch passes int64 offsets[n_reads+1] and NULL lengths).  max_len bounds the
+ * adapter window of every read (it sizes the LDS carve-up); windows longer than max_len or than
+ * the kernel's on-chip capacity WDX_MAX_ADAPTER_SAMPLES are reported WDX_READ_FAIL_UNKNOWN.
+ * Any output pointer except d_status may be NULL. */
+int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                        const int32_t *d_row_len, int64_t stride, int64_t max_len,
+                        int64_t n_reads, const int32_t *d_a_start, const int32_t *d_a_end,
+                        const uint8_t *d_ok, const wdx_seg_params *p, double *d_fpt,
+                        int64_t *d_dwell, double *d_stats, int32_t *d_status, void *stream);
+
+#define WDX_MAX_ADAPTER_SAMPLES 12288
+
+/* ---- fused path: raw adapter rows -> fingerprint -> DTW to the resident refs -> call ------ */
+
+/* As wdx_fingerprint_dev, then DTW of every successful read against the resident refs.
+ * d_dist: (n_reads,nY) float32; d_call: int32[n_reads] = argmin column or -1 for failed reads;
+ * d_counts (nullable): int64[nY+1], INCREMENTED by the per-column call histogram, slot nY =
+ * failed reads.  d_fpt/d_dwell/d_stats are optional as above.  d_work: DEVICE scratch of at
+ * least wdx_demux_workspace_bytes(n_reads, K) bytes. */
+int64_t wdx_demux_workspace_bytes(int64_t n_reads, int32_t barcode_num_events);
+int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                  const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
+                  const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
+                  const wdx_seg_params *p, double *d_fpt, int64_t *d_dwell, double *d_stats,
+                  int32_t *d_status, float *d_dist, int32_t *d_call, int64_t *d_counts,
+                  void *d_work, void *stream);
+
+/* ---- measurement helpers ------------------------------------------------------------------ */
+
+/* Kernel ids for wdx_kernel_time */
+#define WDX_K_FINGERPRINT 0
+#define WDX_K_DTW 1
+#define WDX_K_TRANSPOSE 2
+#define WDX_K_COUNT 3
+/* When enabled, every kernel launch through this context is bracketed by hipEvents on its
+ * stream; wdx_kernel_time() synchronises them and returns accumulated ms and launch count. */
+int wdx_kernel_timing(wdx_ctx *ctx, int enable);
+int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+int wdx_kernel_time_reset(wdx_ctx *ctx);
+
+/* ---- synthetic input generator (bench / tests; spec "wdx-synth v1", warpdemux_amd/synth.py) */
+
+/* Lengths (incl. both 100-sample pads) of reads first_read .. first_read+n-1 -> d_len int64[n] */
+int wdx_synth_lengths_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
+                          int32_t n_barcodes, const int32_t *d_dwell_table /*1024*/,
+                          int64_t *d_len, void *stream);
+/* Fill d_sig (packed, offsets d_off int64[n+1]) and d_barcode int32[n] (nullable). */
+int wdx_synth_fill_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
+                       int32_t n_barcodes, int32_t n_bc_events, float noise_scale, int32_t spikes,
+                       const int32_t *d_dwell_table, const float *d_lead /*160*/,
+                       const float *d_bc /*n_barcodes x 64*/, const int64_t *d_off, float *d_sig,
+                       int32_t *d_barcode, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDX_H */

@@ -1,0 +1,109 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host shims
+validate like the reference, and -- with no GPU here -- every compute entry point fails loudly
+instead of falling back to anything."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from warpdemux_amd import _lib, dist, parallel_distances as pdist, sig_proc, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    return _lib.load().wdx_device_count() > 0
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "wdx.h")).read()
+    declared = set(re.findall(r"\b(wdx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"wdx_seg_params"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.wdx_abi_version() == 1
+
+
+def test_seg_params_struct_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "wdx.h")).read()
+    body = hdr[hdr.index("typedef struct wdx_seg_params {"): hdr.index("} wdx_seg_params;")]
+    fields = re.findall(r"^\s*(int32_t|float)\s+(\w+);", body, flags=re.M)
+    assert [f[1] for f in fields] == [f[0] for f in _lib.SegParamsC._fields_]
+    import ctypes
+    assert ctypes.sizeof(_lib.SegParamsC) == 36
+
+
+def test_no_silent_fallback_without_gpu():
+    if _have_gpu():
+        pytest.skip("GPU present")
+    X, Y = np.zeros((4, 25)), np.zeros((3, 25))
+    with pytest.raises(_lib.WdxError, match="ROCm-capable|HIP|device"):
+        pdist.distance_matrix_to(X, Y, window=15, penalty=0.1, n_jobs=1)
+    with pytest.raises(_lib.WdxError):
+        sig_proc.fingerprint_batch(np.zeros((2, 100), np.float32), [0, 0], [100, 100], sig_proc.SegParams())
+
+
+def test_reference_error_behaviour_is_mirrored():
+    X, Y = np.zeros((4, 25)), np.zeros((3, 25))
+    # parallel_distances.py:70-73
+    with pytest.raises(ValueError, match="block_size must be specified when using parallel."):
+        pdist.distance_matrix_to(X, Y, window=15, penalty=0.1, n_jobs=4)
+    with pytest.raises(ValueError, match="block_size must be specified"):
+        pdist.distance_matrix_to(X, Y, n_jobs=-1)
+    # np.vstack([X, Y]) column mismatch is a ValueError in the reference
+    with pytest.raises(ValueError):
+        pdist.distance_matrix_to(X, np.zeros((3, 24)), n_jobs=1)
+    # sig_proc.py:131-134
+    with pytest.raises(ValueError, match="not recognized"):
+        sig_proc.SegParams(seg_norm="zscore").to_c()
+
+
+def test_install_patches_reference_modules(monkeypatch):
+    import sys
+    import types
+
+    import warpdemux_amd
+
+    pkg = types.ModuleType("warpdemux")
+    pd = types.ModuleType("warpdemux.parallel_distances")
+    pd.distance_matrix_to = lambda *a, **k: "ref"
+    models = types.ModuleType("warpdemux.models")
+    svm = types.ModuleType("warpdemux.models.dtw_svm")
+    svm.distance_matrix_to = pd.distance_matrix_to
+    for name, m in (("warpdemux", pkg), ("warpdemux.parallel_distances", pd), ("warpdemux.models", models),
+                    ("warpdemux.models.dtw_svm", svm)):
+        monkeypatch.setitem(sys.modules, name, m)
+    warpdemux_amd.install()
+    assert pd.distance_matrix_to is pdist.distance_matrix_to
+    assert svm.distance_matrix_to is pdist.distance_matrix_to
+    assert pd.parallel_distance_matrix is pdist.parallel_distance_matrix
+
+
+def test_synth_is_deterministic_and_sane():
+    spec = synth.SynthSpec(n_barcodes=10)
+    a, off, a_s, a_e, bc = synth.generate_packed(spec, 42, 12)
+    b, off2, *_ = synth.generate_packed(spec, 42, 12)
+    assert np.array_equal(a, b) and np.array_equal(off, off2)
+    # shard independence: reads are a function of the GLOBAL read index only
+    c, off3, *_ = synth.generate_packed(spec, 45, 3)
+    assert np.array_equal(c, a[off[3]:off[6]])
+    lens = np.diff(off)
+    assert 3500 < lens.mean() < 6500 and a.dtype == np.float32
+    assert set(bc.tolist()) <= set(range(10))
+    assert np.all(a_s == 100) and np.array_equal(a_e, lens - 100)
+    big = synth.read_layout(spec, np.arange(4000))[3]
+    assert 4500 < big.mean() < 5100
+
+
+def test_shard_ranges_partition_the_reads():
+    for n in (0, 1, 7, 1000, 40_000_000):
+        for world in (1, 2, 3, 8):
+            parts = [dist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert max(hi - lo for lo, hi in parts) <= -(-n // world)
+    with pytest.raises(ValueError):
+        dist.shard_range(10, 2, 2)

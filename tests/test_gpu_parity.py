@@ -1,0 +1,311 @@
+"""Parity of the HIP engine (through the C ABI) against the CPU oracle and the reference-derived
+golden fixtures.  Needs a real MI355X: run with `pytest -m gpu`.
+
+Bar: integer outputs (status, change-point-derived dwell, argmin) bit-exact; float64 fingerprints
+and stats bit-exact (same operation order, no FMA); float32 DTW distances bit-exact against the
+oracle (tolerance the north star allows: 1e-5 relative -- asserted separately so a rounding
+difference in sqrt would be reported as such, not hidden).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import wdx_oracle as orc
+from warpdemux_amd import _lib, parallel_distances as pdist, sig_proc, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north-star tolerance on the float distances
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def _check_dist(got, ref):
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    rel = np.abs(got[fin].astype(np.float64) - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)
+    assert rel.size == 0 or rel.max() <= RTOL, f"max rel err {rel.max()}"
+    assert _same(got, ref), f"not bit-exact: {np.count_nonzero(got != ref)} of {got.size} differ (max rel {rel.max() if rel.size else 0})"
+
+
+# ---------------------------------------------------------------------------------------- DTW ----
+
+@pytest.mark.parametrize("nX,nY,L,w,p", [
+    (1000, 10, 110, 15, 0.1),     # R1 benchmark regime
+    (1000, 4, 110, 15, 0.1),
+    (300, 851, 25, 15, 0.1),      # R2 shipped-model regime (WDX4)
+    (64, 6, 110, 15, 0.0),
+    (5000, 10, 110, 15, 0.1),     # fused-argmin path (grid.x >= 2048 needs more; see below)
+])
+def test_dtw_matrix_regimes(nX, nY, L, w, p):
+    rng = np.random.default_rng(nX * 7 + nY)
+    X, Y = rng.normal(size=(nX, L)), rng.normal(size=(nY, L))
+    ref = orc.dtw_matrix(X, Y, w, p)
+    got, am = pdist.nearest_reference(X, Y, w, p)
+    _check_dist(got, ref)
+    assert np.array_equal(am, np.argmin(ref, axis=1))
+    assert _same(pdist.distance_matrix_to(X, Y, window=w, penalty=p, n_jobs=1), ref)
+
+
+def test_dtw_large_batch_fused_argmin():
+    rng = np.random.default_rng(11)
+    nX, nY, L = 140_000, 10, 110   # > 2048 waves -> in-kernel argmin
+    Y = rng.normal(size=(nY, L))
+    lab = rng.integers(0, nY, nX)
+    X = Y[lab] + 0.7 * rng.normal(size=(nX, L))
+    got, am = pdist.nearest_reference(X, Y, 15, 0.1)
+    sub = rng.choice(nX, 3000, replace=False)
+    ref = orc.dtw_matrix(X[sub], Y, 15, 0.1)
+    _check_dist(got[sub], ref)
+    assert np.array_equal(am, np.argmin(got, axis=1))
+    assert np.array_equal(am[sub], np.argmin(ref, axis=1))
+    assert (am == lab).mean() > 0.95
+
+
+@pytest.mark.parametrize("w", [None, 0, 1, 2, 5, 8, 9, 15, 16, 17, 25, 32, 33, 60, 110, 500])
+@pytest.mark.parametrize("L", [25, 110])
+def test_dtw_windows(w, L):
+    rng = np.random.default_rng(3)
+    X, Y = rng.normal(size=(70, L)), rng.normal(size=(9, L))
+    for p in (0.1, None, 1.5):
+        ref = orc.dtw_matrix(X, Y, w, p)
+        _check_dist(pdist.distance_matrix_to(X, Y, window=w, penalty=p, n_jobs=1), ref)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 14, 15, 16, 28, 29, 30, 31, 57, 200])
+def test_dtw_lengths(L):
+    rng = np.random.default_rng(L)
+    X, Y = rng.normal(size=(65, L)), rng.normal(size=(5, L))
+    _check_dist(pdist.distance_matrix_to(X, Y, window=15, penalty=0.1, n_jobs=1), orc.dtw_matrix(X, Y, 15, 0.1))
+
+
+@pytest.mark.parametrize("nX", [0, 1, 2, 3, 63, 64, 65])
+def test_dtw_few_reads_many_refs(nX):
+    """live mode / per-read calls: lanes run over the references"""
+    rng = np.random.default_rng(5)
+    Y = rng.normal(size=(1368, 25))
+    X = rng.normal(size=(nX, 25))
+    got, am = pdist.nearest_reference(X, Y, 15, 0.1)
+    ref = orc.dtw_matrix(X, Y, 15, 0.1)
+    _check_dist(got, ref)
+    if nX:
+        assert np.array_equal(am, np.argmin(ref, axis=1))
+    assert pdist.distance_matrix_to(X[:0], Y, 15, 0.1, n_jobs=1).shape == (0, 1368)
+    assert pdist.distance_matrix_to(X, Y[:0], 15, 0.1, n_jobs=1).shape == (nX, 0)
+
+
+def test_dtw_nan_inf_and_ties():
+    rng = np.random.default_rng(6)
+    X, Y = rng.normal(size=(130, 110)), rng.normal(size=(10, 110))
+    X[3, 17] = np.nan
+    X[64, 0] = np.nan
+    Y[4, 109] = np.nan
+    Y[7] = Y[2]            # duplicate reference -> exact tie, argmin takes the lower index
+    X[10] = Y[2]           # distance exactly 0 to refs 2 and 7
+    got, am = pdist.nearest_reference(X, Y, 15, 0.1)
+    ref = orc.dtw_matrix(X, Y, 15, 0.1)
+    _check_dist(got, ref)
+    assert np.isnan(got[3]).all() and np.isnan(got[:, 4]).all()
+    assert np.array_equal(am, orc.argmin_rows(ref))
+    assert np.array_equal(am, np.argmin(ref, axis=1))
+    assert got[10, 2] == 0.0 and am[10] == 2
+
+
+def test_dtw_symmetry_and_block_api():
+    rng = np.random.default_rng(8)
+    X = rng.normal(size=(150, 25))
+    D = pdist.parallel_distance_matrix(X, block_size=64, n_jobs=2, window=15, penalty=0.1)
+    assert D.shape == (150, 150) and D.dtype == np.float32
+    assert np.array_equal(D, D.T) and np.all(np.diag(D) == 0)
+    _check_dist(D, orc.dtw_matrix(X, X, 15, 0.1))
+    sub = pdist.parallel_distance_matrix(X, block_size=50, n_jobs=2, subset=((10, 40), (100, 150)), window=15, penalty=0.1)
+    assert _same(sub, D[10:40, 100:150])
+    i, j, blk = pdist.compute_block_distance((np.arange(5, 20), np.arange(30, 33)), X, 15, 0.1)
+    assert _same(blk, D[5:20, 30:33])
+    to = pdist.distance_matrix_to(X[:20], X[20:], window=15, penalty=0.1, block_size=7, n_jobs=4)
+    assert _same(to, D[:20, 20:])
+
+
+def test_refs_cache_distinguishes_content():
+    rng = np.random.default_rng(9)
+    X, Y1 = rng.normal(size=(80, 25)), rng.normal(size=(30, 25))
+    Y2 = Y1.copy()
+    Y2[5, 5] += 1e-9
+    a = pdist.distance_matrix_to(X, Y1, 15, 0.1, n_jobs=1)
+    b = pdist.distance_matrix_to(X, Y2, 15, 0.1, n_jobs=1)
+    c = pdist.distance_matrix_to(X, Y1, 15, 0.2, n_jobs=1)
+    _check_dist(a, orc.dtw_matrix(X, Y1, 15, 0.1))
+    _check_dist(b, orc.dtw_matrix(X, Y2, 15, 0.1))
+    _check_dist(c, orc.dtw_matrix(X, Y1, 15, 0.2))
+
+
+# --------------------------------------------------------------------------------- fingerprint ----
+
+def _params_from(g, k):
+    pad, sig_norm, d, w, E, acc, seg_norm, K = (int(v) for v in g[f"params_{k}"])
+    inv = {0: "none", 1: "mean", 2: "median"}
+    kw = dict(padding=pad, sig_norm=inv[sig_norm], outlier_thresh=float(g[f"thresh_{k}"]),
+              min_obs_per_base=d, running_stat_width=w, num_events=E, accept_less_cpts=bool(acc),
+              seg_norm=inv[seg_norm], barcode_num_events=K)
+    return sig_proc.SegParams(**kw), orc.SegParams(**kw)
+
+
+def test_fingerprint_golden_vectors(golden_dir):
+    """Reference-derived fixtures (tests/golden/make_golden.py) through wdx_fingerprint_batch."""
+    g = np.load(os.path.join(golden_dir, "g4_fingerprint.npz"))
+    n = int(g["n"])
+    seen = set()
+    for k in range(n):
+        tag = str(g[f"tag_{k}"])
+        a_start, a_end, ok = (int(v) for v in g[f"args_{k}"])
+        p_hip, p_orc = _params_from(g, k)
+        row = g[f"row_{k}"]
+        fb = sig_proc.fingerprint_batch(row.reshape(1, -1), [a_start], [a_end], p_hip, success=[ok])
+        st_ref = int(g[f"status_{k}"])
+        assert int(fb.status[0]) == st_ref, f"case {k} ({tag}): status {fb.status[0]} != {st_ref}"
+        seen.add(st_ref)
+        if st_ref != 0:
+            assert np.isnan(fb.fpt).all() and (fb.dwell == 0).all() and np.isnan(fb.stats).all()
+            continue
+        if tag == "noise_free_steps":
+            # exact score ties: the reference's own answer depends on np.argsort's unstable order;
+            # the engine follows the oracle's documented tie rule instead
+            o = orc.fingerprint_one(row, a_start, a_end, p_orc)
+            assert _same(fb.fpt[0], o["fpt"]) and _same(fb.dwell[0], o["dwell"]) and _same(fb.stats[0], o["stats"])
+            continue
+        assert _same(fb.fpt[0], g[f"fpt_{k}"]), f"case {k} ({tag}) fpt"
+        assert _same(fb.dwell[0], g[f"dwell_{k}"]), f"case {k} ({tag}) dwell"
+        assert _same(fb.stats[0], g[f"stats_{k}"]), f"case {k} ({tag}) stats"
+    assert {0, 1, 3, 4, 5} <= seen
+
+
+@pytest.mark.parametrize("K", [25, 110])
+def test_fingerprint_minibatch_vs_oracle(K):
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 5000, 700, 10000)
+    ok = np.ones(700, dtype=np.uint8)
+    ok[[5, 77]] = 0
+    mb[9, 3000:] = np.nan            # NaN tail inside the adapter window
+    a_e[11] = a_s[11] + 50           # tiny adapter -> "unknown"
+    a_e[12] = a_s[12] + 900          # short adapter -> parameter shrink
+    ph = sig_proc.SegParams(barcode_num_events=K)
+    po = orc.SegParams(barcode_num_events=K)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph, success=ok)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po, ok=ok)
+    assert np.array_equal(fb.status, status)
+    assert (status == 0).sum() > 650 and {1, 4, 5} <= set(status.tolist())
+    good = status == 0
+    assert _same(fb.dwell[good], dwell[good])
+    assert _same(fb.fpt[good], fpt[good])
+    assert _same(fb.stats[good], stats[good])
+    assert np.isnan(fb.fpt[~good]).all()
+
+
+def test_fingerprint_long_rows_and_capacity():
+    """adapter windows up to the on-chip capacity (1024-thread / one-workgroup-per-CU carve-up)"""
+    rng = np.random.default_rng(12)
+    n, stride = 6, 14000
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    lens = [12288, 12000, 9000, 12289, 14000, 7000]
+    for i, ln in enumerate(lens):
+        mb[i, :ln] = (np.repeat(rng.normal(80, 15, ln // 40 + 1), 40)[:ln] + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array(lens, dtype=np.int32)
+    ph, po = sig_proc.SegParams(padding=0), orc.SegParams(padding=0)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
+    for i, ln in enumerate(lens):
+        if ln > 12288:
+            assert fb.status[i] == 5   # documented engine limit (WDX_MAX_ADAPTER_SAMPLES)
+        else:
+            assert fb.status[i] == status[i] == 0
+            assert _same(fb.fpt[i], fpt[i]) and _same(fb.dwell[i], dwell[i]) and _same(fb.stats[i], stats[i])
+
+
+def test_detect_results_to_fpt_shim():
+    from types import SimpleNamespace as NS
+
+    spec = synth.SynthSpec(n_barcodes=4)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 0, 6, 8000)
+    spc = NS(sig_extract=NS(padding=100, normalization="none"), core=NS(sig_norm_outlier_thresh=5.0),
+             segmentation=NS(num_events=110, min_obs_per_base=6, running_stat_width=12, accept_less_cpts=False,
+                             consensus_refinement=False, normalization="mean", barcode_num_events=25))
+    drs = [sig_proc.DetectResults(True, "", int(a_s[i]), int(a_e[i])) for i in range(6)]
+    drs[2] = sig_proc.DetectResults(False, "no adapter found", None, None)
+    drs[3] = sig_proc.DetectResults(True, "", 100, 130)
+    res = sig_proc.detect_results_to_fpt_batch(mb, spc, drs, read_ids=[f"r{i}" for i in range(6)])
+    assert [r.success for r in res] == [True, True, False, False, True, True]
+    assert res[2].fail_reason == "no adapter found" and res[2].barcode_fpt.size == 0
+    assert res[3].fail_reason == "unknown" and res[3].detect_results is None
+    o = orc.fingerprint_one(mb[0], a_s[0], a_e[0], orc.SegParams())
+    assert _same(res[0].barcode_fpt, o["fpt"]) and res[0].read_id == "r0"
+    assert res[0].adapter_event_mean == o["stats"][2]
+    one = sig_proc.detect_results_to_fpt(mb[1], spc, drs[1])
+    assert _same(one.barcode_fpt, res[1].barcode_fpt)
+    with pytest.raises(NotImplementedError):
+        spc.sig_extract.normalization = "mean"
+        sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+    with pytest.raises(ValueError):
+        spc.sig_extract.normalization = "bogus"
+        sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+
+
+# ------------------------------------------------------------------------ fused device pipeline ----
+
+def test_device_synth_matches_numpy_and_fused_pipeline():
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K = 110
+    # references: fingerprints of low-noise template reads through the oracle
+    clean = synth.SynthSpec(n_barcodes=10, noise_sigma=0.25, spikes=False)
+    refs = np.zeros((10, K))
+    rid, found = 0, set()
+    while len(found) < 10:
+        s, b = synth.generate_read(clean, rid)
+        if b not in found:
+            o = orc.fingerprint_one(s, synth.PAD, s.size - synth.PAD, orc.SegParams(barcode_num_events=K))
+            assert o["status"] == 0
+            refs[b] = o["fpt"]
+            found.add(b)
+        rid += 1
+    eng = DemuxEngine(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
+    n = 3000
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 1_000_000, n)
+    hs, ho, hs_s, hs_e, hb = synth.generate_packed(spec, 1_000_000, 64)
+    torch.cuda.synchronize()
+    assert np.array_equal(off[:65].cpu().numpy(), ho)
+    assert np.array_equal(sig[: ho[-1]].cpu().numpy(), hs)   # device generator == NumPy generator, bitwise
+    assert np.array_equal(bc[:64].cpu().numpy(), hb)
+    res = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len + 0, want_fpt=True)
+    torch.cuda.synchronize()
+    sig_h, off_h = sig.cpu().numpy(), off.cpu().numpy()
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig_h, off_h, a_s.cpu().numpy(), a_e.cpu().numpy(),
+                                                       orc.SegParams(barcode_num_events=K))
+    assert np.array_equal(res.status.cpu().numpy(), status)
+    good = status == 0
+    assert good.mean() > 0.99
+    assert _same(res.fpt.cpu().numpy()[good], fpt[good])
+    D = orc.dtw_matrix(fpt[good], refs, 15, 0.1)
+    _check_dist(res.dist.cpu().numpy()[good], D)
+    call = res.call.cpu().numpy()
+    assert np.array_equal(call[good], np.argmin(D, axis=1))
+    assert (call[~good] == -1).all()
+    counts = res.counts.cpu().numpy()
+    exp = np.bincount(np.where(good, call, 10), minlength=11)
+    assert np.array_equal(counts, exp) and counts.sum() == n
+    acc = (call[good] == bc.cpu().numpy()[good]).mean()
+    assert acc > 0.9, acc
+    # second call accumulates into the same histogram
+    res2 = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, counts=res.counts)
+    torch.cuda.synchronize()
+    assert np.array_equal(res2.counts.cpu().numpy(), 2 * exp)
+    eng.close()

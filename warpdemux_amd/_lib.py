@@ -1,0 +1,181 @@
+"""ctypes binding of libwdx_hip.so (C ABI: include/wdx.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C warpdemux_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing or no MI355X is visible, every entry
+point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwdx_hip.so")
+
+WDX_SUCCESS = 0
+WDX_ERR_INVALID = -1
+WDX_ERR_NO_DEVICE = -2
+WDX_ERR_HIP = -3
+WDX_ERR_UNSUPPORTED = -4
+WDX_ERR_NO_REFS = -5
+
+K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT = 0, 1, 2, 3
+
+NORM_CODES = {"none": 0, "mean": 1, "median": 2}
+
+# every symbol include/wdx.h declares (tests check the .so exports each of them)
+EXPORTS = [
+    "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
+    "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_dtw_matrix_dev",
+    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
+    "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
+    "wdx_synth_fill_dev",
+]
+
+
+class SegParamsC(C.Structure):
+    """wdx_seg_params (include/wdx.h)"""
+
+    _fields_ = [
+        ("padding", C.c_int32),
+        ("sig_norm", C.c_int32),
+        ("outlier_thresh", C.c_float),
+        ("min_obs_per_base", C.c_int32),
+        ("running_stat_width", C.c_int32),
+        ("num_events", C.c_int32),
+        ("accept_less_cpts", C.c_int32),
+        ("seg_norm", C.c_int32),
+        ("barcode_num_events", C.c_int32),
+    ]
+
+
+class WdxError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen the engine; raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise WdxError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C warpdemux_amd/csrc` (there is no CPU fallback)"
+            )
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+        P = C.POINTER
+        L.wdx_abi_version.restype = C.c_int
+        L.wdx_abi_version.argtypes = []
+        L.wdx_last_error.restype = C.c_char_p
+        L.wdx_last_error.argtypes = []
+        L.wdx_device_count.restype = C.c_int
+        L.wdx_device_count.argtypes = []
+        L.wdx_ctx_create.restype = C.c_int
+        L.wdx_ctx_create.argtypes = [C.c_int, P(vp)]
+        L.wdx_ctx_destroy.restype = None
+        L.wdx_ctx_destroy.argtypes = [vp]
+        L.wdx_ctx_synchronize.restype = C.c_int
+        L.wdx_ctx_synchronize.argtypes = [vp, vp]
+        L.wdx_dtw_matrix.restype = C.c_int
+        L.wdx_dtw_matrix.argtypes = [vp, vp, i64, vp, i64, i64, i32, f64, vp, vp]
+        L.wdx_set_refs.restype = C.c_int
+        L.wdx_set_refs.argtypes = [vp, vp, i64, i64, i32, f64]
+        L.wdx_dtw_matrix_dev.restype = C.c_int
+        L.wdx_dtw_matrix_dev.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.wdx_fingerprint_batch.restype = C.c_int
+        L.wdx_fingerprint_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
+        L.wdx_fingerprint_dev.restype = C.c_int
+        L.wdx_fingerprint_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp]
+        L.wdx_demux_workspace_bytes.restype = i64
+        L.wdx_demux_workspace_bytes.argtypes = [i64, i32]
+        L.wdx_demux_dev.restype = C.c_int
+        L.wdx_demux_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.wdx_kernel_timing.restype = C.c_int
+        L.wdx_kernel_timing.argtypes = [vp, C.c_int]
+        L.wdx_kernel_time.restype = C.c_int
+        L.wdx_kernel_time.argtypes = [vp, C.c_int, P(f64), P(i64)]
+        L.wdx_kernel_time_reset.restype = C.c_int
+        L.wdx_kernel_time_reset.argtypes = [vp]
+        L.wdx_synth_lengths_dev.restype = C.c_int
+        L.wdx_synth_lengths_dev.argtypes = [vp, u64, i64, i64, i32, vp, vp, vp]
+        L.wdx_synth_fill_dev.restype = C.c_int
+        L.wdx_synth_fill_dev.argtypes = [vp, u64, i64, i64, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp]
+        if L.wdx_abi_version() != 1:
+            raise WdxError("libwdx_hip.so ABI version mismatch")
+        _lib = L
+        return L
+
+
+def check(rc: int):
+    """Map a WDX_ERR_* code to the exception the reference's Python would raise."""
+    if rc == WDX_SUCCESS:
+        return
+    msg = load().wdx_last_error().decode("utf-8", "replace")
+    if rc == WDX_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == WDX_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise WdxError(f"[wdx {rc}] {msg}")
+
+
+def ptr(a):
+    """void* of a NumPy array (host) -- None passes NULL."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owns one wdx_ctx (device workspaces + resident reference set).  Created lazily per process
+    and per device so that fork()ed workers (file_proc.py:1197) each initialise HIP themselves."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = C.c_void_p()
+        check(L.wdx_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self._L = L
+        self.device = int(device)
+        self.pid = os.getpid()
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise WdxError("context destroyed")
+        return self._h
+
+    def close(self):
+        if self._h is not None and self.pid == os.getpid():
+            self._L.wdx_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_ctx: dict[tuple[int, int, int], Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Per-(process, thread, device) context.  Device defaults to $WDX_DEVICE or 0."""
+    if device is None:
+        device = int(os.environ.get("WDX_DEVICE", "0"))
+    key = (os.getpid(), threading.get_ident(), device)
+    c = _ctx.get(key)
+    if c is None:
+        c = Context(device)
+        _ctx[key] = c
+    return c

@@ -1,0 +1,569 @@
+// C ABI of libwdx_hip.so (include/wdx.h): context, workspaces, host<->device plumbing.
+// The arithmetic lives in wdx_dtw.hip / wdx_fingerprint.hip; nothing here computes results.
+#include "wdx_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+namespace wdx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+struct Buffer {  // grow-only device workspace
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return WDX_SUCCESS;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            p = nullptr;
+            return WDX_ERR_HIP;
+        }
+        bytes = want;
+        return WDX_SUCCESS;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+constexpr int kNumTimed = 4;
+
+}  // namespace wdx
+
+using namespace wdx;
+
+struct wdx_ctx {
+    int device = 0;
+    std::mutex mu;
+    DtwRefs refs;
+    Buffer refs_pad, refs_T, refs_nan;
+    // host-buffer call workspaces
+    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[kNumTimed];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double acc_ms[kNumTimed] = {0, 0, 0, 0};
+    int64_t launches[kNumTimed] = {0, 0, 0, 0};
+};
+
+namespace {
+
+struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
+    wdx_ctx *c;
+    int id;
+    hipStream_t s;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
+        if (!c->timing) return;
+        if (!c->pool.empty()) {
+            ev = c->pool.back();
+            c->pool.pop_back();
+        } else {
+            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+                ev = {nullptr, nullptr};
+                return;
+            }
+        }
+        (void)hipEventRecord(ev.first, s);
+    }
+    ~Timed() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, s);
+        c->pending[id].push_back(ev);
+    }
+};
+
+int check_ctx(wdx_ctx *ctx) {
+    if (!ctx) {
+        set_error("null context");
+        return WDX_ERR_INVALID;
+    }
+    WDX_HIP_TRY(hipSetDevice(ctx->device));
+    return WDX_SUCCESS;
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// (re)build the resident reference set from a HOST array
+int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
+                    double penalty, hipStream_t stream) {
+    if (nY < 0 || L <= 0 || (nY > 0 && !Y)) {
+        set_error("set_refs: need nY >= 0, L > 0 and a non-null Y");
+        return WDX_ERR_INVALID;
+    }
+    if (penalty != penalty) {
+        set_error("set_refs: penalty is NaN");
+        return WDX_ERR_INVALID;
+    }
+    const int w_eff = (window <= 0 || window > L) ? (int)L : window;
+    uint64_t h = fnv1a(Y, (size_t)(nY * L) * sizeof(double));
+    h = fnv1a(&nY, sizeof(nY), h);
+    h = fnv1a(&L, sizeof(L), h);
+    DtwRefs &R = ctx->refs;
+    if (R.window != 0 && R.content_hash == h && R.nY == nY && R.L == L) {
+        R.window = w_eff;  // same samples: only the scalars may have changed
+        R.penalty = penalty;
+        return WDX_SUCCESS;
+    }
+    const int halo = kMaxRegWindow - 1;
+    const int64_t Lpad = L + 2 * halo;
+    const int64_t ldT = round_up(nY > 0 ? nY : 1, 64);
+    int rc;
+    if ((rc = ctx->refs_pad.ensure((size_t)(nY > 0 ? nY : 1) * Lpad * sizeof(double)))) return rc;
+    if ((rc = ctx->refs_T.ensure((size_t)L * ldT * sizeof(double)))) return rc;
+    if ((rc = ctx->refs_nan.ensure((size_t)ldT))) return rc;
+    if ((rc = ctx->tmp0.ensure((size_t)(nY > 0 ? nY : 1) * L * sizeof(double)))) return rc;
+    if (nY > 0) {
+        WDX_HIP_TRY(hipMemcpyAsync(ctx->tmp0.p, Y, (size_t)(nY * L) * sizeof(double),
+                                   hipMemcpyHostToDevice, stream));
+        WDX_HIP_TRY(hipMemsetAsync(ctx->refs_T.p, 0, (size_t)L * ldT * sizeof(double), stream));
+        if ((rc = launch_pad_rows((const double *)ctx->tmp0.p, nY, L, (double *)ctx->refs_pad.p,
+                                  Lpad, halo, (uint8_t *)ctx->refs_nan.p, stream)))
+            return rc;
+        if ((rc = launch_transpose((const double *)ctx->tmp0.p, nY, L, (double *)ctx->refs_T.p, ldT,
+                                   nullptr, stream)))
+            return rc;
+        WDX_HIP_TRY(hipStreamSynchronize(stream));  // tmp0 is reused by later calls
+    }
+    R.pad = (double *)ctx->refs_pad.p;
+    R.T = (double *)ctx->refs_T.p;
+    R.has_nan = (uint8_t *)ctx->refs_nan.p;
+    R.nY = nY;
+    R.L = L;
+    R.Lpad = Lpad;
+    R.ldT = ldT;
+    R.halo = halo;
+    R.window = w_eff;
+    R.penalty = penalty;
+    R.content_hash = h;
+    return WDX_SUCCESS;
+}
+
+// DTW of device rows dX (nX, L) against the resident refs -> d_out (nX, nY) [+ argmin]
+int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int32_t *d_argmin,
+                   hipStream_t stream) {
+    DtwRefs &R = ctx->refs;
+    if (R.window == 0) {
+        set_error("no reference set: call wdx_set_refs first");
+        return WDX_ERR_NO_REFS;
+    }
+    if (nX == 0 || R.nY == 0) return WDX_SUCCESS;
+    int rc;
+    const int64_t L = R.L;
+    const int64_t sb = dtw_scratch_bytes(L, R.window);
+    if (sb && (rc = ctx->scratch.ensure((size_t)sb))) return rc;
+    // lanes = reads unless there are too few of them to fill a wave and there are more refs
+    const bool lanes_are_reads = nX >= 64 || nX >= R.nY;
+    if (lanes_are_reads) {
+        const int64_t ld = round_up(nX, 64);
+        if ((rc = ctx->tmp1.ensure((size_t)L * ld * sizeof(double)))) return rc;
+        if ((rc = ctx->tmp2.ensure((size_t)ld))) return rc;
+        {
+            Timed t(ctx, WDX_K_TRANSPOSE, stream);
+            if ((rc = launch_transpose(dX, nX, L, (double *)ctx->tmp1.p, ld, (uint8_t *)ctx->tmp2.p,
+                                       stream)))
+                return rc;
+        }
+        Timed t(ctx, WDX_K_DTW, stream);
+        if (sb && d_argmin) {
+            if ((rc = launch_dtw((const double *)ctx->tmp1.p, ld, nX, (const uint8_t *)ctx->tmp2.p,
+                                 R.pad, R.Lpad, R.halo, R.nY, R.has_nan, L, R.window, R.penalty,
+                                 d_out, R.nY, 1, nullptr, ctx->scratch.p, (int64_t)ctx->scratch.bytes,
+                                 stream)))
+                return rc;
+            return launch_argmin(d_out, nX, R.nY, d_argmin, stream);
+        }
+        return launch_dtw((const double *)ctx->tmp1.p, ld, nX, (const uint8_t *)ctx->tmp2.p, R.pad,
+                          R.Lpad, R.halo, R.nY, R.has_nan, L, R.window, R.penalty, d_out, R.nY, 1,
+                          d_argmin, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream);
+    }
+    // few reads, many refs (live / per-read calls): lanes = refs, the read is the uniform operand
+    const int halo = kMaxRegWindow - 1;
+    const int64_t Lpad = L + 2 * halo;
+    if ((rc = ctx->tmp1.ensure((size_t)nX * Lpad * sizeof(double)))) return rc;
+    if ((rc = ctx->tmp2.ensure((size_t)round_up(nX, 64)))) return rc;
+    {
+        Timed t(ctx, WDX_K_TRANSPOSE, stream);
+        if ((rc = launch_pad_rows(dX, nX, L, (double *)ctx->tmp1.p, Lpad, halo,
+                                  (uint8_t *)ctx->tmp2.p, stream)))
+            return rc;
+    }
+    {
+        Timed t(ctx, WDX_K_DTW, stream);
+        if ((rc = launch_dtw(R.T, R.ldT, R.nY, R.has_nan, (const double *)ctx->tmp1.p, Lpad, halo,
+                             nX, (const uint8_t *)ctx->tmp2.p, L, R.window, R.penalty, d_out, 1,
+                             R.nY, nullptr, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream)))
+            return rc;
+    }
+    if (d_argmin) return launch_argmin(d_out, nX, R.nY, d_argmin, stream);
+    return WDX_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wdx_abi_version(void) { return WDX_ABI_VERSION; }
+
+const char *wdx_last_error(void) { return g_err; }
+
+int wdx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return WDX_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+int wdx_ctx_create(int device, wdx_ctx **out) {
+    if (!out) {
+        set_error("null out pointer");
+        return WDX_ERR_INVALID;
+    }
+    *out = nullptr;
+    int n = wdx_device_count();
+    if (n < 0) return n;
+    if (n == 0) {
+        set_error("no HIP device visible");
+        return WDX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return WDX_ERR_INVALID;
+    }
+    WDX_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    WDX_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 only", device,
+                  prop.gcnArchName);
+        return WDX_ERR_NO_DEVICE;
+    }
+    wdx_ctx *c = new wdx_ctx();
+    c->device = device;
+    *out = c;
+    return WDX_SUCCESS;
+}
+
+void wdx_ctx_destroy(wdx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
+                      &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch})
+        b->release();
+    for (int k = 0; k < kNumTimed; ++k)
+        for (auto &e : ctx->pending[k]) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    for (auto &e : ctx->pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete ctx;
+}
+
+int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return WDX_SUCCESS;
+}
+
+int wdx_set_refs(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
+                 double penalty) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return set_refs_locked(ctx, Y, nY, L, window, penalty, nullptr);
+}
+
+int wdx_dtw_matrix_dev(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int32_t *d_argmin,
+                       void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (nX < 0 || (nX > 0 && (!dX || !d_out))) {
+        set_error("dtw_matrix_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return dtw_dev_locked(ctx, dX, nX, d_out, d_argmin, (hipStream_t)stream);
+}
+
+int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, int64_t nY,
+                   int64_t L, int32_t window, double penalty, float *out, int32_t *argmin) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (nX < 0 || nY < 0 || L <= 0 || (nX > 0 && !X) || (nY > 0 && !Y) ||
+        (nX > 0 && nY > 0 && !out)) {
+        set_error("dtw_matrix: need nX,nY >= 0, L > 0 and non-null buffers");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipStream_t s = nullptr;
+    if ((rc = set_refs_locked(ctx, Y, nY, L, window, penalty, s))) return rc;
+    if (nX == 0 || nY == 0) {
+        if (argmin)
+            for (int64_t i = 0; i < nX; ++i) argmin[i] = 0;
+        return WDX_SUCCESS;
+    }
+    const size_t xb = (size_t)(nX * L) * sizeof(double), ob = (size_t)(nX * nY) * sizeof(float);
+    if ((rc = ctx->in0.ensure(xb))) return rc;
+    if ((rc = ctx->out0.ensure(ob))) return rc;
+    if (argmin && (rc = ctx->out1.ensure((size_t)nX * sizeof(int32_t)))) return rc;
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X, xb, hipMemcpyHostToDevice, s));
+    if ((rc = dtw_dev_locked(ctx, (const double *)ctx->in0.p, nX, (float *)ctx->out0.p,
+                             argmin ? (int32_t *)ctx->out1.p : nullptr, s)))
+        return rc;
+    WDX_HIP_TRY(hipMemcpyAsync(out, ctx->out0.p, ob, hipMemcpyDeviceToHost, s));
+    if (argmin)
+        WDX_HIP_TRY(hipMemcpyAsync(argmin, ctx->out1.p, (size_t)nX * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipStreamSynchronize(s));
+    return WDX_SUCCESS;
+}
+
+int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                        const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
+                        const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
+                        const wdx_seg_params *p, double *d_fpt, int64_t *d_dwell, double *d_stats,
+                        int32_t *d_status, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_reads < 0 || !p || (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status))) {
+        set_error("fingerprint_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    Timed t(ctx, WDX_K_FINGERPRINT, (hipStream_t)stream);
+    return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
+                              d_a_end, d_ok, *p, d_fpt, d_dwell, d_stats, d_status,
+                              (hipStream_t)stream);
+}
+
+int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                          const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                          const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
+                          int32_t *status) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_reads < 0 || stride < 0 || !p ||
+        (n_reads > 0 && (!sig || !a_start || !a_end || !fpt || !dwell || !stats || !status))) {
+        set_error("fingerprint_batch: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipStream_t s = nullptr;
+    const int64_t K = p->barcode_num_events;
+    if (K < 1) {
+        set_error("barcode_num_events must be >= 1");
+        return WDX_ERR_INVALID;
+    }
+    // exact bound on the adapter window over this batch (extract_adapter, sig_proc.py:388-389)
+    int64_t max_len = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        if (ok && !ok[r]) continue;
+        int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
+        if (st < 0) st = 0;
+        if (en > stride) en = stride;
+        if (en - st > max_len) max_len = en - st;
+    }
+    const size_t sb = (size_t)(n_reads * stride) * sizeof(float);
+    if ((rc = ctx->in0.ensure(sb ? sb : 4))) return rc;
+    if ((rc = ctx->in1.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->in2.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->in3.ensure((size_t)n_reads))) return rc;
+    if ((rc = ctx->out0.ensure((size_t)(n_reads * K) * 8))) return rc;
+    if ((rc = ctx->out1.ensure((size_t)(n_reads * K) * 8))) return rc;
+    if ((rc = ctx->out2.ensure((size_t)n_reads * 6 * 8))) return rc;
+    if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, sig, sb, hipMemcpyHostToDevice, s));
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    if (ok) WDX_HIP_TRY(hipMemcpyAsync(ctx->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
+    {
+        Timed t(ctx, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint((const float *)ctx->in0.p, nullptr, nullptr, stride, max_len,
+                                     n_reads, (const int32_t *)ctx->in1.p,
+                                     (const int32_t *)ctx->in2.p,
+                                     ok ? (const uint8_t *)ctx->in3.p : nullptr, *p,
+                                     (double *)ctx->out0.p, (int64_t *)ctx->out1.p,
+                                     (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s)))
+            return rc;
+    }
+    WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipMemcpyAsync(dwell, ctx->out1.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipMemcpyAsync(stats, ctx->out2.p, (size_t)n_reads * 48, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipMemcpyAsync(status, ctx->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipStreamSynchronize(s));
+    return WDX_SUCCESS;
+}
+
+int64_t wdx_demux_workspace_bytes(int64_t n_reads, int32_t K) {
+    if (n_reads < 0 || K < 1) return 0;
+    const int64_t ld = round_up(n_reads > 0 ? n_reads : 1, 64);
+    // [fpt (n,K) f64][fptT (K,ld) f64][nan flags ld]
+    return n_reads * K * 8 + (int64_t)K * ld * 8 + ld + 256;
+}
+
+int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                  const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
+                  const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
+                  const wdx_seg_params *p, double *d_fpt, int64_t *d_dwell, double *d_stats,
+                  int32_t *d_status, float *d_dist, int32_t *d_call, int64_t *d_counts, void *d_work,
+                  void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_reads < 0 || !p ||
+        (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status || !d_dist || !d_call || !d_work))) {
+        set_error("demux_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    DtwRefs &R = ctx->refs;
+    if (R.window == 0) {
+        set_error("no reference set: call wdx_set_refs first");
+        return WDX_ERR_NO_REFS;
+    }
+    const int64_t K = p->barcode_num_events;
+    if (K != R.L) {
+        set_error("barcode_num_events (%lld) != reference length (%lld)", (long long)K,
+                  (long long)R.L);
+        return WDX_ERR_INVALID;
+    }
+    if (dtw_scratch_bytes(R.L, R.window)) {
+        set_error("demux_dev needs window <= %d", kMaxRegWindow);
+        return WDX_ERR_UNSUPPORTED;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ld = round_up(n_reads, 64);
+    unsigned char *w = (unsigned char *)d_work;
+    double *fpt = d_fpt ? d_fpt : (double *)w;
+    double *fptT = (double *)(w + n_reads * K * 8);
+    uint8_t *flags = (uint8_t *)(w + n_reads * K * 8 + K * ld * 8);
+    {
+        Timed t(ctx, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
+                                     d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s)))
+            return rc;
+    }
+    {
+        Timed t(ctx, WDX_K_TRANSPOSE, s);
+        if ((rc = launch_transpose(fpt, n_reads, K, fptT, ld, flags, s))) return rc;
+    }
+    {
+        Timed t(ctx, WDX_K_DTW, s);
+        if ((rc = launch_dtw(fptT, ld, n_reads, flags, R.pad, R.Lpad, R.halo, R.nY, R.has_nan, R.L,
+                             R.window, R.penalty, d_dist, R.nY, 1, d_call, nullptr, 0, s)))
+            return rc;
+    }
+    Timed t(ctx, WDX_K_COUNT, s);
+    return launch_count_calls(d_call, d_status, n_reads, R.nY, d_counts, s);
+}
+
+int wdx_kernel_timing(wdx_ctx *ctx, int enable) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->timing = enable != 0;
+    return WDX_SUCCESS;
+}
+
+int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (kernel_id < 0 || kernel_id >= kNumTimed) {
+        set_error("kernel id out of range");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (auto &e : ctx->pending[kernel_id]) {
+        WDX_HIP_TRY(hipEventSynchronize(e.second));
+        float ms = 0;
+        WDX_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        ctx->acc_ms[kernel_id] += ms;
+        ctx->launches[kernel_id] += 1;
+        ctx->pool.push_back(e);
+    }
+    ctx->pending[kernel_id].clear();
+    if (total_ms) *total_ms = ctx->acc_ms[kernel_id];
+    if (launches) *launches = ctx->launches[kernel_id];
+    return WDX_SUCCESS;
+}
+
+int wdx_kernel_time_reset(wdx_ctx *ctx) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (int k = 0; k < kNumTimed; ++k) {
+        for (auto &e : ctx->pending[k]) {
+            (void)hipEventSynchronize(e.second);
+            ctx->pool.push_back(e);
+        }
+        ctx->pending[k].clear();
+        ctx->acc_ms[k] = 0;
+        ctx->launches[k] = 0;
+    }
+    return WDX_SUCCESS;
+}
+
+int wdx_synth_lengths_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
+                          int32_t n_barcodes, const int32_t *d_dwell_table, int64_t *d_len,
+                          void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return launch_synth_lengths(seed, first_read, n_reads, n_barcodes, d_dwell_table, d_len,
+                                (hipStream_t)stream);
+}
+
+int wdx_synth_fill_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
+                       int32_t n_barcodes, int32_t n_bc_events, float noise_scale, int32_t spikes,
+                       const int32_t *d_dwell_table, const float *d_lead, const float *d_bc,
+                       const int64_t *d_off, float *d_sig, int32_t *d_barcode, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return launch_synth_fill(seed, first_read, n_reads, n_barcodes, n_bc_events, noise_scale, spikes,
+                             d_dwell_table, d_lead, d_bc, d_off, d_sig, d_barcode,
+                             (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Shared declarations of the libwdx_hip translation units (internal; the public ABI is include/wdx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wdx.h"
+
+namespace wdx {
+
+// Thread-local error message backing wdx_last_error().
+void set_error(const char *fmt, ...);
+
+#define WDX_HIP_TRY(expr)                                                                 \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::wdx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                             __FILE__, __LINE__);                                         \
+            return WDX_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+// ---- DTW (wdx_dtw.hip) -----------------------------------------------------------------------
+// Largest Sakoe-Chiba window handled by the register-band kernel; wider / unbanded problems with
+// L > this go to the scratch-row kernel.
+constexpr int kMaxRegWindow = 32;
+
+struct DtwRefs {  // resident reference set, both layouts (see DESIGN.md "DTW data layout")
+    double *pad = nullptr;   // (nY, Lpad) row-major, Lpad = L + 2*halo, series starts at +halo
+    double *T = nullptr;     // (L, ldT) read-minor (series along columns)
+    uint8_t *has_nan = nullptr;  // nY flags
+    int64_t nY = 0, L = 0, Lpad = 0, ldT = 0;
+    int halo = 0;
+    int window = 0;  // effective window (1..L), 0 = not set
+    double penalty = 0;
+    uint64_t content_hash = 0;
+};
+
+// lanes run over the columns of AT (L, ldA) [nA series]; the uniform operand is Bpad (nB rows).
+// out[a*sA + b*sB] = (float)dtw(a, b).  d_argmin (nullable) is only legal when the lanes are the
+// reads (sA == nB, sB == 1): int32[nA].
+int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan /*nullable*/,
+               const double *Bpad, int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan,
+               int64_t L, int window, double penalty, float *out, int64_t sA, int64_t sB,
+               int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream);
+int64_t dtw_scratch_bytes(int64_t L, int window);
+
+// (n, L) row-major -> (L, ld) read-minor, plus per-series NaN flag (nullable)
+int launch_transpose(const double *src, int64_t n, int64_t L, double *dstT, int64_t ld,
+                     uint8_t *has_nan, hipStream_t stream);
+int launch_nan_flags_T(const double *T, int64_t ld, int64_t n, int64_t L, uint8_t *flags,
+                       hipStream_t stream);
+// (n, L) row-major -> (n, Lpad) with `halo` zero entries either side, plus NaN flags
+int launch_pad_rows(const double *src, int64_t n, int64_t L, double *dst, int64_t Lpad, int halo,
+                    uint8_t *has_nan, hipStream_t stream);
+// per-row argmin of a float32 (n, m) matrix with np.argmin semantics
+int launch_argmin(const float *D, int64_t n, int64_t m, int32_t *out, hipStream_t stream);
+// call[r] = status[r] ? -1 : call[r]; counts[call or m] += 1
+int launch_count_calls(int32_t *call, const int32_t *status /*nullable*/, int64_t n, int64_t m,
+                       int64_t *counts /*nullable*/, hipStream_t stream);
+
+// ---- fingerprint (wdx_fingerprint.hip) ---------------------------------------------------------
+int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
+                       int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
+                       const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
+                       double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
+                       hipStream_t stream);
+
+// ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------
+int launch_synth_lengths(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,
+                         const int32_t *dwell_table, int64_t *d_len, hipStream_t stream);
+int launch_synth_fill(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,
+                      int32_t n_bc_events, float noise_scale, int32_t spikes,
+                      const int32_t *dwell_table, const float *lead, const float *bc,
+                      const int64_t *off, float *sig, int32_t *barcode, hipStream_t stream);
+
+}  // namespace wdx

@@ -1,0 +1,426 @@
+// Banded DTW distance matrix for gfx950 -- stage B of the hot path.
+//
+// Replaces dtaidistance.dtw.distance_matrix as called from
+// /root/reference/warpdemux/parallel_distances.py:34-43 and :59-67 (SURVEY.md §8 rows B1-B3,
+// recurrence in App. A):  D[i+1][j+1] = (a_i-b_j)^2 + min(D[i][j], D[i][j+1]+p2, D[i+1][j]+p2),
+// band |i-j| <= w-1, result sqrt(D[L][L]), float64 arithmetic, float32 output.
+//
+// Mapping (DESIGN.md "DTW kernels"): one LANE per (series-a, series-b) pair.  Lanes of a wave run
+// over different a-series (read-minor layout AT[L][ldA] -> every row load is one coalesced 512-B
+// wave access); the b-series is UNIFORM across the wave, so its samples arrive through the scalar
+// data path (s_load) and cost no vector issue slots.  The Sakoe-Chiba band of the previous DP row
+// lives in 2W-1 float64 registers per lane and is updated in place, left to right; there is no
+// cross-lane traffic and no LDS.  All float64 ops are issued un-fused (-ffp-contract=off) in the
+// oracle's order, except min(up+p2, left+p2) == min(up,left)+p2, which is exact because rounding
+// is monotone.  No MFMA: this is a min-plus recurrence.
+#include "wdx_common.h"
+
+#include <math.h>
+
+namespace wdx {
+
+#define WDX_INF __builtin_huge_val()
+
+// v_min_f64 without the canonicalising v_max_f64 x,x that fmin() costs per call in IEEE mode when
+// the compiler cannot prove an operand quiet (the loop-carried band registers).  The operands here
+// are always results of float64 adds, +0.0 or +inf -- never signalling NaNs; NaN inputs are
+// handled by the per-series flags, not by the recurrence.
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int W, bool MASKED>
+__device__ __forceinline__ void dtw_row(double (&r)[2 * W - 1], double x,
+                                        const double *__restrict__ yi, double p2, int jbase,
+                                        int jlo, int jhi) {
+    constexpr int B = 2 * W - 1;
+    double left = WDX_INF;
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+        double d = x - yi[c];
+        d = d * d;
+        double up = (c + 1 < B) ? r[c + 1] : WDX_INF;
+        double t = (c == 0 ? up : min_f64(up, left)) + p2;  // left of the first band cell is +inf
+        t = min_f64(t, r[c]);
+        double v = d + t;
+        if (MASKED) {
+            int j = jbase + c;
+            v = (j < jlo || j > jhi) ? WDX_INF : v;
+        }
+        r[c] = v;
+        left = v;
+    }
+}
+
+// np.argmin running update on float32 values (first minimum; first NaN wins outright)
+struct ArgminAcc {
+    float best = __builtin_huge_valf();
+    int idx = 0;
+    bool nan = false;
+    bool any = false;
+    __device__ __forceinline__ void push(float v, int i) {
+        if (nan) return;
+        if (v != v) {
+            nan = true;
+            idx = i;
+        } else if (!any || v < best) {
+            best = v;
+            idx = i;
+        }
+        any = true;
+    }
+};
+
+template <int W, bool EXACT_W>
+__global__ __launch_bounds__(64) void dtw_band_kernel(
+    const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
+    const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
+    const uint8_t *__restrict__ b_nan, int L, int w, double p2, float *__restrict__ out,
+    int64_t sA, int64_t sB, int32_t *__restrict__ argmin, int refs_per_block) {
+    constexpr int B = 2 * W - 1;
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = a < nA;
+    const int64_t al = active ? a : nA - 1;
+    const int b0 = blockIdx.y * refs_per_block;
+    const int b1 = min(nB, b0 + refs_per_block);
+    const bool anan = a_nan ? (a_nan[al] != 0) : false;
+    const double *__restrict__ xp = AT + al;
+    ArgminAcc acc;
+
+    for (int b = b0; b < b1; ++b) {
+        const double *__restrict__ y = Bpad + (int64_t)b * Lpad + (halo - (W - 1));
+        double r[B];
+#pragma unroll
+        for (int c = 0; c < B; ++c) r[c] = WDX_INF;
+        r[W - 1] = 0.0;
+        double xn = xp[0];
+        int i = 0;
+        if (EXACT_W) {
+            const int head_end = min(W - 1, L);          // rows whose band leaves [0, L)
+            const int body_end = max(head_end, L - W + 1);
+            for (; i < head_end; ++i) {
+                double x = xn;
+                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
+            }
+            for (; i < body_end; ++i) {
+                double x = xn;
+                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                dtw_row<W, false>(r, x, y + i, p2, 0, 0, 0);
+            }
+            for (; i < L; ++i) {
+                double x = xn;
+                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
+            }
+        } else {
+            for (; i < L; ++i) {
+                double x = xn;
+                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), max(0, i - (w - 1)),
+                                 min(L - 1, i + (w - 1)));
+            }
+        }
+        double res = sqrt(r[W - 1]);
+        if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
+        float f = (float)res;
+        if (active) out[a * sA + (int64_t)b * sB] = f;
+        acc.push(f, b);
+    }
+    if (argmin && active) argmin[a] = acc.idx;
+}
+
+// Any window / any length: two rolling DP rows per lane in global scratch, element (row, j) of lane
+// t at scratch[(row*(L+1)+j)*nT + t] (coalesced across lanes).  Slow path; correctness first.
+__global__ __launch_bounds__(64) void dtw_scratch_kernel(
+    const double *__restrict__ AT, int64_t ldA, int64_t a_base, int64_t nA,
+    const uint8_t *__restrict__ a_nan, const double *__restrict__ Bpad, int64_t Lpad, int halo,
+    int nB, const uint8_t *__restrict__ b_nan, int L, int w, double p2, float *__restrict__ out,
+    int64_t sA, int64_t sB, double *__restrict__ scratch, int64_t nT) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t a = a_base + t;
+    const bool active = a < nA && t < nT;
+    const int64_t al = a < nA ? a : nA - 1;
+    const int64_t tl = t < nT ? t : nT - 1;
+    const bool anan = a_nan ? (a_nan[al] != 0) : false;
+    double *row0 = scratch + tl;
+    const int64_t rs = (int64_t)(L + 1) * nT;
+    for (int b = 0; b < nB; ++b) {
+        const double *__restrict__ y = Bpad + (int64_t)b * Lpad + halo;
+        double *prev = row0, *cur = row0 + rs;
+        for (int j = 0; j <= L; ++j) prev[(int64_t)j * nT] = WDX_INF;
+        prev[0] = 0.0;
+        for (int i = 0; i < L; ++i) {
+            const double x = AT[(int64_t)i * ldA + al];
+            const int j0 = max(0, i - (w - 1));
+            const int j1 = min(L, i + w);
+            cur[(int64_t)j0 * nT] = WDX_INF;
+            if (j1 + 1 <= L) cur[(int64_t)(j1 + 1) * nT] = WDX_INF;
+            double left = WDX_INF;
+            double diag = prev[(int64_t)j0 * nT];
+            for (int j = j0; j < j1; ++j) {
+                double d = x - y[j];
+                d = d * d;
+                double up = prev[(int64_t)(j + 1) * nT];
+                double tt = min_f64(up, left) + p2;
+                tt = min_f64(tt, diag);
+                double v = d + tt;
+                cur[(int64_t)(j + 1) * nT] = v;
+                left = v;
+                diag = up;
+            }
+            double *sw = prev;
+            prev = cur;
+            cur = sw;
+        }
+        double res = sqrt(prev[(int64_t)L * nT]);
+        if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
+        if (active) out[a * sA + (int64_t)b * sB] = (float)res;
+    }
+}
+
+int64_t dtw_scratch_bytes(int64_t L, int window) {
+    if (window <= kMaxRegWindow) return 0;
+    return 2 * (L + 1) * 65536 * (int64_t)sizeof(double);
+}
+
+int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, const double *Bpad,
+               int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan, int64_t L, int window,
+               double penalty, float *out, int64_t sA, int64_t sB, int32_t *d_argmin,
+               void *d_scratch, int64_t scratch_bytes, hipStream_t stream) {
+    if (nA == 0 || nB == 0) return WDX_SUCCESS;
+    if (L <= 0) {
+        set_error("DTW series length must be positive");
+        return WDX_ERR_INVALID;
+    }
+    int w = (window <= 0 || window > L) ? (int)L : window;  // |i-j| <= w-1 is vacuous beyond L
+    const double p2 = penalty * penalty;
+    if (w > kMaxRegWindow) {
+        const int64_t nT = 65536;
+        if (scratch_bytes < dtw_scratch_bytes(L, w) || !d_scratch) {
+            set_error("DTW scratch too small for window %d", w);
+            return WDX_ERR_INVALID;
+        }
+        if (d_argmin) {
+            set_error("fused argmin is not available on the scratch-row DTW path");
+            return WDX_ERR_INVALID;
+        }
+        for (int64_t a_base = 0; a_base < nA; a_base += nT) {
+            int64_t n = nA - a_base < nT ? nA - a_base : nT;
+            dim3 grid((unsigned)((n + 63) / 64));
+            hipLaunchKernelGGL(dtw_scratch_kernel, grid, dim3(64), 0, stream, AT, ldA, a_base, nA,
+                               a_nan, Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB,
+                               (double *)d_scratch, nT);
+        }
+        WDX_HIP_TRY(hipGetLastError());
+        return WDX_SUCCESS;
+    }
+    if (halo < kMaxRegWindow - 1) {
+        set_error("reference rows need a halo of %d samples", kMaxRegWindow - 1);
+        return WDX_ERR_INVALID;
+    }
+    const int64_t gx = (nA + 63) / 64;
+    // one block walks `rpb` refs.  With enough a-series to fill 256 CUs x 8 waves a single block
+    // walks them all and (if asked) folds the argmin in; otherwise the refs are split over grid.y
+    // and the argmin is a second, tiny kernel.
+    int32_t *fused_argmin = nullptr;
+    int rpb = (int)nB;
+    if (gx >= 2048 || nB == 1) {
+        fused_argmin = d_argmin;
+    } else {
+        int64_t want_y = (2048 + gx - 1) / gx;
+        if (want_y > nB) want_y = nB;
+        rpb = (int)((nB + want_y - 1) / want_y);
+    }
+    if (d_argmin && (sA != nB || sB != 1)) {
+        set_error("argmin needs the row-major (nA, nB) output layout");
+        return WDX_ERR_INVALID;
+    }
+    dim3 grid((unsigned)gx, (unsigned)((nB + rpb - 1) / rpb));
+#define WDX_LAUNCH_BAND(WW, EX)                                                                   \
+    hipLaunchKernelGGL((dtw_band_kernel<WW, EX>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, \
+                       Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB, fused_argmin, rpb)
+    if (w == 15) {
+        WDX_LAUNCH_BAND(15, true);
+    } else if (w <= 8) {
+        WDX_LAUNCH_BAND(8, false);
+    } else if (w <= 16) {
+        WDX_LAUNCH_BAND(16, false);
+    } else {
+        WDX_LAUNCH_BAND(32, false);
+    }
+#undef WDX_LAUNCH_BAND
+    WDX_HIP_TRY(hipGetLastError());
+    if (d_argmin && !fused_argmin) return launch_argmin(out, nA, nB, d_argmin, stream);
+    return WDX_SUCCESS;
+}
+
+// ---- layout helpers ----------------------------------------------------------------------------
+
+__global__ void transpose_kernel(const double *__restrict__ src, int64_t n, int64_t L,
+                                 double *__restrict__ dst, int64_t ld) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;  // series
+    const int64_t c0 = (int64_t)blockIdx.y * 32;  // sample
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int64_t r = r0 + k, c = c0 + threadIdx.x;
+        if (r < n && c < L) tile[k][threadIdx.x] = src[r * L + c];
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        int64_t c = c0 + k, r = r0 + threadIdx.x;
+        if (r < n && c < L) dst[c * ld + r] = tile[threadIdx.x][k];
+    }
+}
+
+__global__ void nan_flags_T_kernel(const double *__restrict__ T, int64_t ld, int64_t n, int64_t L,
+                                   uint8_t *__restrict__ flags) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    bool f = false;
+    for (int64_t i = 0; i < L; ++i) {
+        double v = T[i * ld + a];
+        f |= (v != v);
+    }
+    flags[a] = f ? 1 : 0;
+}
+
+int launch_transpose(const double *src, int64_t n, int64_t L, double *dstT, int64_t ld,
+                     uint8_t *has_nan, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((L + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, stream, src, n, L, dstT, ld);
+    if (has_nan)
+        hipLaunchKernelGGL(nan_flags_T_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           stream, dstT, ld, n, L, has_nan);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+int launch_nan_flags_T(const double *T, int64_t ld, int64_t n, int64_t L, uint8_t *flags,
+                       hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(nan_flags_T_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       T, ld, n, L, flags);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+__global__ void pad_rows_kernel(const double *__restrict__ src, int64_t n, int64_t L,
+                                double *__restrict__ dst, int64_t Lpad, int halo,
+                                uint8_t *__restrict__ has_nan) {
+    // one wave per series
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    bool f = false;
+    for (int64_t c = lane; c < Lpad; c += 64) {
+        int64_t s = c - halo;
+        double v = (s >= 0 && s < L) ? src[r * L + s] : 0.0;
+        f |= (v != v);
+        dst[r * Lpad + c] = v;
+    }
+    unsigned long long m = __ballot(f);
+    if (has_nan && lane == 0) has_nan[r] = m ? 1 : 0;
+}
+
+int launch_pad_rows(const double *src, int64_t n, int64_t L, double *dst, int64_t Lpad, int halo,
+                    uint8_t *has_nan, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, n,
+                       L, dst, Lpad, halo, has_nan);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+// ---- B3: argmin + call histogram -----------------------------------------------------------------
+
+__global__ void argmin_rows_kernel(const float *__restrict__ D, int64_t n, int64_t m,
+                                   int32_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    // key: (is_nan desc, value asc, index asc) -- np.argmin
+    float bv = __builtin_huge_valf();
+    int bi = 0x7fffffff;
+    bool bn = false;
+    for (int64_t c = lane; c < m; c += 64) {
+        float v = D[r * m + c];
+        bool isn = v != v;
+        bool better = bn ? false : (isn ? true : (bi == 0x7fffffff || v < bv));
+        if (better) {
+            bv = v;
+            bi = (int)c;
+            bn = isn;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        float ov = __shfl_down(bv, off);
+        int oi = __shfl_down(bi, off);
+        int on = __shfl_down((int)bn, off);
+        bool take;
+        if (oi == 0x7fffffff) take = false;
+        else if (bi == 0x7fffffff) take = true;
+        else if (on != (int)bn) take = on != 0;
+        else if (bn) take = oi < bi;
+        else take = (ov < bv) || (ov == bv && oi < bi);
+        if (take) {
+            bv = ov;
+            bi = oi;
+            bn = on != 0;
+        }
+    }
+    if (lane == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
+}
+
+int launch_argmin(const float *D, int64_t n, int64_t m, int32_t *out, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(argmin_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, D,
+                       n, m, out);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+__global__ void count_calls_kernel(int32_t *__restrict__ call, const int32_t *__restrict__ status,
+                                   int64_t n, int m, unsigned long long *__restrict__ counts) {
+    extern __shared__ unsigned int hist[];
+    const bool use_lds = m + 1 <= 4096;
+    if (use_lds) {
+        for (int k = threadIdx.x; k <= m; k += blockDim.x) hist[k] = 0;
+        __syncthreads();
+    }
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        int c = call[r];
+        if (status && status[r] != 0) {
+            c = -1;
+            call[r] = -1;
+        }
+        int bin = (c < 0 || c >= m) ? m : c;
+        if (counts) {
+            if (use_lds) atomicAdd(&hist[bin], 1u);
+            else atomicAdd(&counts[bin], 1ull);
+        }
+    }
+    if (use_lds && counts) {
+        __syncthreads();
+        for (int k = threadIdx.x; k <= m; k += blockDim.x)
+            if (hist[k]) atomicAdd(&counts[k], (unsigned long long)hist[k]);
+    }
+}
+
+int launch_count_calls(int32_t *call, const int32_t *status, int64_t n, int64_t m, int64_t *counts,
+                       hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    size_t lds = (m + 1 <= 4096) ? (size_t)(m + 1) * sizeof(unsigned int) : 0;
+    hipLaunchKernelGGL(count_calls_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, call,
+                       status, n, (int)m, (unsigned long long *)counts);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+}  // namespace wdx

@@ -1,0 +1,745 @@
+// Per-read adapter fingerprinting for gfx950 -- stage A of the hot path.
+//
+// Replaces the per-read Python loop /root/reference/warpdemux/file_proc.py:418-428 over
+// sig_proc.py:394-605 `detect_results_to_fpt` (non-refinement branch) and the Cython primitives
+// segmentation/_c_segmentation.pyx:41-53 (c_new_means) and :124-161 (c_windowed_t_test), plus the
+// scipy.signal.find_peaks(distance=) call at sig_proc.py:183.
+//
+// Mapping (DESIGN.md "Fingerprint kernel"): ONE WORKGROUP PER READ.  The adapter samples are read
+// from HBM exactly once (coalesced), and everything else -- the clipped float32 signal, the
+// float64 t-score curve, the peak state bytes, change-points and event means -- lives in LDS until
+// the K-point fingerprint is written.  All float64 arithmetic is issued un-fused and in the
+// reference's operation order, so t-scores, change-points and fingerprints are bit-identical to
+// the CPU path.  Phases:
+//   P0 load            HBM -> LDS (float32)
+//   P1 MAD clip        two exact medians by range-adaptive radix select over LDS (A1)
+//   P2 t-score         window mean/variance M[q],V[q] once per window start (m2(pos) == m1(pos+W)
+//                      operation for operation), tiled through LDS, float64 (A3)
+//   P3 peaks           local maxima incl. plateaus; greedy minimum-distance suppression as a
+//                      fixed-point iteration over the position-space state bytes (A4, App. B)
+//   P4 top-E           radix select on the float64 score bits (A4)
+//   P5 boundaries      ordered compaction -> change-points
+//   P6 event means     sequential float64 sums per segment (A5)
+//   P7 normalise+stats numpy pairwise mean/std, medians by rank counting, tail-K extract (A6)
+#include "wdx_common.h"
+
+namespace wdx {
+
+constexpr int kMaxW = 64;        // cap on running_stat_width
+constexpr int kTile = 512;       // t-score tile, positions
+constexpr int kMaxEvents = 253;  // cap on num_events (E + 2 boundaries <= 255)
+constexpr int kSegCap = kMaxEvents + 1;
+
+enum : unsigned char { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_DROPPED = 3, ST_SELECTED = 4 };
+
+struct FpArgs {
+    const float *sig;
+    const int64_t *row_off;
+    const int32_t *row_len;
+    int64_t stride;
+    int64_t n_reads;
+    const int32_t *a_start;
+    const int32_t *a_end;
+    const uint8_t *ok;
+    wdx_seg_params p;
+    double *fpt;
+    int64_t *dwell;
+    double *stats;
+    int32_t *status;
+    int cap;  // LDS capacity in samples
+};
+
+struct alignas(8) FpShared {
+    unsigned long long red64[16];
+    unsigned red_a[16], red_b[16], red_c[16];
+    unsigned sel_bin, sel_k;
+    unsigned long long sel_key64;
+    int flag;
+    int count;
+    float med, mad;
+    double mean, sd;
+    double stat[6];
+};
+
+// ---- block primitives ----------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned f32_key(float x) {
+    unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void block_minmax_count(unsigned kmin, unsigned kmax, unsigned cnt,
+                                                   FpShared &sh, unsigned &omin, unsigned &omax,
+                                                   unsigned &ocnt) {
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, off));
+        kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, off));
+        cnt += (unsigned)__shfl_xor((int)cnt, off);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sh.red_a[wave] = kmin;
+        sh.red_b[wave] = kmax;
+        sh.red_c[wave] = cnt;
+    }
+    __syncthreads();
+    omin = 0xffffffffu;
+    omax = 0;
+    ocnt = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) {
+        omin = min(omin, sh.red_a[k]);
+        omax = max(omax, sh.red_b[k]);
+        ocnt += sh.red_c[k];
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void block_minmax64_count(unsigned long long kmin,
+                                                     unsigned long long kmax, unsigned cnt,
+                                                     FpShared &sh, unsigned long long &omin,
+                                                     unsigned long long &omax, unsigned &ocnt) {
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        cnt += (unsigned)__shfl_xor((int)cnt, off);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sh.red64[wave] = kmin;
+        sh.red_c[wave] = cnt;
+    }
+    __syncthreads();
+    omin = ~0ull;
+    ocnt = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) {
+        omin = sh.red64[k] < omin ? sh.red64[k] : omin;
+        ocnt += sh.red_c[k];
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.red64[wave] = kmax;
+    __syncthreads();
+    omax = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) omax = sh.red64[k] > omax ? sh.red64[k] : omax;
+}
+
+// After the histogram of one digit is complete: wave 0 finds the bin holding rank k.
+__device__ __forceinline__ void select_scan_bins(unsigned *hist, unsigned k, FpShared &sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
+                 c3 = hist[4 * lane + 3];
+        unsigned s = c0 + c1 + c2 + c3, incl = s;
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned t = (unsigned)__shfl_up((int)incl, off);
+            if (lane >= off) incl += t;
+        }
+        unsigned e = incl - s;
+        if (k >= e && k < e + s) {
+            unsigned bin = 4 * lane, kk = k - e;
+            if (kk >= c0) { kk -= c0; bin++;
+                if (kk >= c1) { kk -= c1; bin++;
+                    if (kk >= c2) { kk -= c2; bin++; } } }
+            sh.sel_bin = bin;
+            sh.sel_k = kk;
+        }
+    }
+}
+
+// k-th smallest (0-based) 32-bit key among the valid items; keyfn(i, key) -> valid.
+// All threads must call; 0 <= k < n_valid; kmin/kmax are the exact extremes of the valid keys.
+template <int BLOCK, class KeyFn>
+__device__ unsigned block_select_u32(KeyFn keyfn, int n, unsigned k, unsigned kmin, unsigned kmax,
+                                     unsigned *hist, FpShared &sh) {
+    const unsigned range = kmax - kmin;
+    int rb = range ? 32 - __clz((int)range) : 0;
+    unsigned prefix = 0;
+    while (rb > 0) {
+        const int b = rb < 8 ? rb : 8;
+        const int shift = rb - b;
+        for (int t = threadIdx.x; t < 256; t += BLOCK) hist[t] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += BLOCK) {
+            unsigned key;
+            if (keyfn(i, key)) {
+                unsigned d = key - kmin;
+                unsigned hi = rb >= 32 ? 0u : (d >> rb);
+                if (hi == prefix) atomicAdd(&hist[(d >> shift) & ((1u << b) - 1u)], 1u);
+            }
+        }
+        __syncthreads();
+        select_scan_bins(hist, k, sh);
+        __syncthreads();
+        prefix = (prefix << b) | sh.sel_bin;
+        k = sh.sel_k;
+        rb = shift;
+    }
+    return kmin + prefix;
+}
+
+template <int BLOCK, class KeyFn>
+__device__ unsigned long long block_select_u64(KeyFn keyfn, int n, unsigned k,
+                                               unsigned long long kmin, unsigned long long kmax,
+                                               unsigned *hist, FpShared &sh) {
+    const unsigned long long range = kmax - kmin;
+    int rb = range ? 64 - __clzll((long long)range) : 0;
+    unsigned long long prefix = 0;
+    while (rb > 0) {
+        const int b = rb < 8 ? rb : 8;
+        const int shift = rb - b;
+        for (int t = threadIdx.x; t < 256; t += BLOCK) hist[t] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += BLOCK) {
+            unsigned long long key;
+            if (keyfn(i, key)) {
+                unsigned long long d = key - kmin;
+                unsigned long long hi = rb >= 64 ? 0ull : (d >> rb);
+                if (hi == prefix) atomicAdd(&hist[(unsigned)(d >> shift) & ((1u << b) - 1u)], 1u);
+            }
+        }
+        __syncthreads();
+        select_scan_bins(hist, k, sh);
+        __syncthreads();
+        prefix = (prefix << b) | sh.sel_bin;
+        k = sh.sel_k;
+        rb = shift;
+    }
+    return kmin + prefix;
+}
+
+// np.nanmedian over the float32 values val(i) (NaN = invalid): exact, float32 result.
+template <int BLOCK, class ValFn>
+__device__ float block_nanmedian_f32(ValFn val, int n, unsigned *hist, FpShared &sh) {
+    unsigned kmin = 0xffffffffu, kmax = 0, cnt = 0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        float v = val(i);
+        if (v == v) {
+            unsigned k = f32_key(v);
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+            cnt++;
+        }
+    }
+    unsigned gmin, gmax, m;
+    block_minmax_count<BLOCK>(kmin, kmax, cnt, sh, gmin, gmax, m);
+    if (m == 0) return __builtin_nanf("");
+    auto keyfn = [&](int i, unsigned &key) {
+        float v = val(i);
+        key = f32_key(v);
+        return v == v;
+    };
+    const unsigned h = m / 2;
+    if (m & 1) return key_f32(block_select_u32<BLOCK>(keyfn, n, h, gmin, gmax, hist, sh));
+    // even: ranks h-1 and h.  khi = klo if more than h keys are <= klo, else the next larger key.
+    const unsigned klo = block_select_u32<BLOCK>(keyfn, n, h - 1, gmin, gmax, hist, sh);
+    unsigned nxt = 0xffffffffu, dummy = 0, le = 0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        unsigned key;
+        if (keyfn(i, key)) {
+            if (key <= klo) le++;
+            else nxt = min(nxt, key);
+        }
+    }
+    unsigned gnxt, gdummy, gle;
+    block_minmax_count<BLOCK>(nxt, dummy, le, sh, gnxt, gdummy, gle);
+    const unsigned khi = gle > h ? klo : gnxt;
+    const float s = key_f32(klo) + key_f32(khi);
+    return s / 2.0f;
+}
+
+// numpy pairwise float64 summation (loops_utils.h.src::pairwise_sum), single thread.
+__device__ __forceinline__ double np_pairwise_leaf(const double *p, int n) {  // n <= 128
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; ++i) res += p[i];
+    } else {
+        double r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4], r5 = p[5], r6 = p[6],
+               r7 = p[7];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) {
+            r0 += p[i]; r1 += p[i + 1]; r2 += p[i + 2]; r3 += p[i + 3];
+            r4 += p[i + 4]; r5 += p[i + 5]; r6 += p[i + 6]; r7 += p[i + 7];
+        }
+        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += p[i];
+    }
+    return res;
+}
+// n <= 256 (kSegCap = 254): at most one level of the recursion
+__device__ double np_pairwise_sum_dev(const double *a, int n) {
+    if (n <= 128) return np_pairwise_leaf(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_leaf(a, n2) + np_pairwise_leaf(a + n2, n - n2);
+}
+
+// np.median of n <= kSegCap float64 values in LDS (no NaN) by rank counting; result via sh.stat[slot]
+template <int BLOCK>
+__device__ void block_small_median(const double *a, int n, FpShared &sh, int slot) {
+    const int klo = (n - 1) / 2, khi = n / 2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        const double v = a[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double u = a[j];
+            rank += (u < v) || (u == v && j < i);
+        }
+        if (rank == klo) sh.red64[0] = (unsigned long long)__double_as_longlong(v);
+        if (rank == khi) sh.red64[1] = (unsigned long long)__double_as_longlong(v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lo = __longlong_as_double((long long)sh.red64[0]);
+        double hi = __longlong_as_double((long long)sh.red64[1]);
+        sh.stat[slot] = (n & 1) ? hi : (lo + hi) / 2.0;
+    }
+    __syncthreads();
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const wdx_seg_params &P = A.p;
+    const int K = P.barcode_num_events;
+    const int E = P.num_events;
+
+    // LDS carve-up (every region starts 8-byte aligned; cap is a multiple of 64)
+    double *scores = reinterpret_cast<double *>(smem);                    // cap
+    double *Mt = scores + A.cap;                                          // kTile + kMaxW
+    double *Vt = Mt + (kTile + kMaxW);                                    // kTile + kMaxW
+    double *ev = Vt + (kTile + kMaxW);                                    // kSegCap
+    double *zz = ev + kSegCap;                                            // kSegCap
+    double *tmp = zz + kSegCap;                                           // kSegCap
+    FpShared &sh = *reinterpret_cast<FpShared *>(tmp + kSegCap);
+    float *sig = reinterpret_cast<float *>(&sh + 1);                      // cap
+    unsigned *hist = reinterpret_cast<unsigned *>(sig + A.cap);           // 256
+    int *cpts = reinterpret_cast<int *>(hist + 256);                      // kSegCap + 1
+    // the peak-state bytes are live only after the last t-score tile: they reuse the tile buffers
+    // whenever they fit, else a dedicated tail region
+    unsigned char *state = (A.cap <= (int)((kTile + kMaxW) * 16))
+                               ? reinterpret_cast<unsigned char *>(Mt)
+                               : reinterpret_cast<unsigned char *>(cpts + kSegCap + 1);
+
+    int status = WDX_READ_OK;
+
+    auto finish = [&](int st) {
+        // failed reads: NaN fingerprint / stats, zero dwell (block-uniform call)
+        if (st != WDX_READ_OK) {
+            for (int i = tid; i < K; i += BLOCK) {
+                if (A.fpt) A.fpt[r * K + i] = __builtin_nan("");
+                if (A.dwell) A.dwell[r * K + i] = 0;
+            }
+            if (A.stats && tid < 6) A.stats[r * 6 + tid] = __builtin_nan("");
+        }
+        if (tid == 0) A.status[r] = st;
+    };
+
+    if (A.ok && !A.ok[r]) {
+        finish(WDX_READ_FAIL_DETECT);
+        return;
+    }
+
+    // ---- A0 extract_adapter (sig_proc.py:382-391) --------------------------------------------------
+    const int64_t row_off = A.row_off ? A.row_off[r] : r * A.stride;
+    const int64_t row_len = A.row_len ? (int64_t)A.row_len[r]
+                                      : (A.row_off ? A.row_off[r + 1] - A.row_off[r] : A.stride);
+    int64_t start = (int64_t)A.a_start[r] - P.padding;
+    if (start < 0) start = 0;
+    int64_t stop = (int64_t)A.a_end[r] + P.padding;
+    if (stop > row_len) stop = row_len;
+    int64_t n64 = stop - start;
+    if (n64 < 0) n64 = 0;
+    if (n64 > A.cap) {
+        finish(WDX_READ_FAIL_UNKNOWN);
+        return;
+    }
+    const int n = (int)n64;
+
+    // ---- P0: HBM -> LDS ----------------------------------------------------------------------------
+    {
+        const float *__restrict__ src = A.sig + row_off + start;
+        for (int i = tid; i < n; i += BLOCK) sig[i] = src[i];
+    }
+    __syncthreads();
+
+    // ---- P1: MAD outlier clip (sig_proc.py:421-431), float32 ---------------------------------------
+    {
+        const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
+        const float mad =
+            block_nanmedian_f32<BLOCK>([&](int i) { return fabsf(sig[i] - med); }, n, hist, sh);
+        const float tm = P.outlier_thresh * mad;
+        const float lo = med - tm, hi = med + tm;
+        const bool bad = (lo != lo) || (hi != hi);
+        __syncthreads();
+        for (int i = tid; i < n; i += BLOCK) {
+            float v = sig[i];
+            if (v == v) {
+                if (bad) v = __builtin_nanf("");
+                else {
+                    if (!(v > lo)) v = lo;
+                    if (!(v < hi)) v = hi;
+                }
+                sig[i] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- A2: optional signal normalisation (sig_proc.py:433-446); "none" in every shipped config ----
+    if (n > 0 && P.sig_norm == WDX_NORM_MEDIAN) {
+        const float shift = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
+        const float scale =
+            block_nanmedian_f32<BLOCK>([&](int i) { return fabsf(sig[i] - shift); }, n, hist, sh);
+        __syncthreads();
+        for (int i = tid; i < n; i += BLOCK) sig[i] = (sig[i] - shift) / scale;
+        __syncthreads();
+    } else if (n > 0 && P.sig_norm != WDX_NORM_NONE) {
+        finish(WDX_READ_FAIL_SIGNORM);  // host rejects WDX_NORM_MEAN up front; unknown codes fail here
+        return;
+    }
+
+    // ---- parameter shrink (sig_proc.py:526-533), Python round() == rint() ---------------------------
+    int d_eff = (int)rint((double)n / (double)E / 2.0);
+    if (P.min_obs_per_base < d_eff) d_eff = P.min_obs_per_base;
+    int W = (int)rint((double)n / (double)E);
+    if (P.running_stat_width < W) W = P.running_stat_width;
+
+    // ---- P2: windowed t-statistic (_c_segmentation.pyx:124-161) -------------------------------------
+    int ns = n - 2 * W;
+    if (ns < 0 || (ns > 0 && W == 0)) ns = 0;  // the Cython call raises -> zeros(0)
+    if (d_eff < 1) {                            // scipy: `distance` must be >= 1 -> "unknown"
+        finish(WDX_READ_FAIL_UNKNOWN);
+        return;
+    }
+    {
+        const double Wd = (double)W;
+        const int nq = n - W + 1;  // window starts
+        for (int t0 = 0; t0 < ns; t0 += kTile) {
+            const int qend = min(t0 + kTile + W, nq);
+            for (int q = t0 + tid; q < qend; q += BLOCK) {
+                double m = 0.0;
+                for (int k = 0; k < W; ++k) m += (double)sig[q + k];
+                m /= Wd;
+                double v = 0.0;
+                for (int k = 0; k < W; ++k) {
+                    const double df = (double)sig[q + k] - m;
+                    v += df * df;
+                }
+                Mt[q - t0] = m;
+                Vt[q - t0] = v;
+            }
+            __syncthreads();
+            const int pend = min(t0 + kTile, ns);
+            for (int pos = t0 + tid; pos < pend; pos += BLOCK) {
+                const double m1 = Mt[pos - t0], m2 = Mt[pos - t0 + W];
+                const double vs = Vt[pos - t0] + Vt[pos - t0 + W];
+                double s;
+                if (vs == 0) s = 0.0;
+                else if (m1 > m2) s = (m1 - m2) / sqrt(vs);
+                else s = (m2 - m1) / sqrt(vs);
+                scores[pos] = s;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- P3: find_peaks(scores, distance=d_eff) ----------------------------------
+    for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
+    __syncthreads();
+    for (int i = 1 + tid; i < ns - 1; i += BLOCK) {
+        const double s = scores[i];
+        if (scores[i - 1] < s) {
+            int ia = i + 1;
+            while (ia < ns - 1 && scores[ia] == s) ++ia;
+            if (scores[ia] < s) state[(i + ia - 1) / 2] = ST_UNDECIDED;
+        }
+    }
+    __syncthreads();
+    {
+        // greedy suppression by priority == fixed point of: a peak is KEPT once every higher-priority
+        // peak closer than d_eff is DROPPED, and DROPPED as soon as one of them is KEPT.
+        // priority order: score, ties -> larger position first (stable argsort read from the end).
+        const int D1 = d_eff - 1;
+        for (;;) {
+            int pending = 0;
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] != ST_UNDECIDED) continue;
+                const double s = scores[i];
+                bool kept_near = false, wait = false;
+                const int lo = max(0, i - D1), hi = min(ns - 1, i + D1);
+                for (int q = lo; q <= hi; ++q) {
+                    if (q == i) continue;
+                    const unsigned char st = state[q];
+                    if (st == ST_KEPT) kept_near = true;
+                    else if (st == ST_UNDECIDED) {
+                        const double sq = scores[q];
+                        if (sq > s || (sq == s && q > i)) wait = true;
+                    }
+                }
+                if (kept_near) state[i] = ST_DROPPED;
+                else if (!wait) state[i] = ST_KEPT;
+                else pending = 1;
+            }
+            if (!__syncthreads_or(pending)) break;
+        }
+    }
+
+    // ---- P4: keep the E highest peaks (sig_proc.py:185-188) -----------------------------------------
+    int nsel;
+    {
+        unsigned long long kmin = ~0ull, kmax = 0;
+        unsigned cnt = 0;
+        for (int i = tid; i < ns; i += BLOCK) {
+            if (state[i] == ST_KEPT) {
+                unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+                cnt++;
+            }
+        }
+        unsigned long long gmin, gmax;
+        unsigned nk;
+        block_minmax64_count<BLOCK>(kmin, kmax, cnt, sh, gmin, gmax, nk);
+        if ((int)nk < E && !P.accept_less_cpts) {
+            finish(WDX_READ_FAIL_SEGMENT);
+            return;
+        }
+        if (nk == 0) {
+            finish(WDX_READ_FAIL_UNKNOWN);  // valid_cpts[0] on an empty array
+            return;
+        }
+        if ((int)nk <= E) {
+            nsel = (int)nk;
+            __syncthreads();
+            for (int i = tid; i < ns; i += BLOCK)
+                if (state[i] == ST_KEPT) state[i] = ST_SELECTED;
+        } else {
+            nsel = E;
+            auto keyfn = [&](int i, unsigned long long &key) {
+                key = (unsigned long long)__double_as_longlong(scores[i]);
+                return state[i] == ST_KEPT;
+            };
+            const unsigned long long T =
+                block_select_u64<BLOCK>(keyfn, ns, nk - (unsigned)E, gmin, gmax, hist, sh);
+            unsigned gt = 0, eq = 0, z0 = 0xffffffffu;
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] == ST_KEPT) {
+                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                    gt += k > T;
+                    eq += k == T;
+                }
+            }
+            unsigned ggt, geq, dmy;
+            block_minmax_count<BLOCK>(z0, gt, eq, sh, dmy, dmy, geq);  // geq = sum(eq)
+            block_minmax_count<BLOCK>(z0, 0u, gt, sh, dmy, dmy, ggt);  // ggt = sum(gt)
+            const unsigned need = (unsigned)E - ggt;  // 1 <= need <= geq
+            __syncthreads();
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] == ST_KEPT) {
+                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                    if (k > T || (k == T && need == geq)) state[i] = ST_SELECTED;
+                }
+            }
+            __syncthreads();
+            if (need != geq && tid == 0) {
+                // exact score ties at the cut: the stable order keeps the LAST `need` of them
+                unsigned left = need;
+                for (int i = ns - 1; i >= 0 && left; --i) {
+                    if (state[i] == ST_KEPT &&
+                        (unsigned long long)__double_as_longlong(scores[i]) == T) {
+                        state[i] = ST_SELECTED;
+                        --left;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- P5: boundaries 0, peaks+W (ascending), n  (sig_proc.py:188-196) -----------------------------
+    {
+        const int chunk = (ns + BLOCK - 1) / BLOCK;
+        const int c0 = tid * chunk, c1 = min(ns, c0 + chunk);
+        int local = 0;
+        for (int i = c0; i < c1; ++i) local += state[i] == ST_SELECTED;
+        // block exclusive scan of `local`
+        int incl = local;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) sh.red_a[wave] = (unsigned)incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += (int)sh.red_a[k];
+        int o = base + incl - local;
+        for (int i = c0; i < c1; ++i)
+            if (state[i] == ST_SELECTED) cpts[1 + o++] = i + W;
+        if (tid == 0) {
+            cpts[0] = 0;
+            cpts[nsel + 1] = n;
+        }
+        __syncthreads();
+    }
+    const int nseg = nsel + 1;
+
+    // ---- P6: event means (_c_segmentation.pyx:41-53), sequential float64 sums ------------------------
+    for (int s = tid; s < nseg; s += BLOCK) {
+        const int b = cpts[s], e = cpts[s + 1];
+        double sum = 0.0;
+        for (int i = b; i < e; ++i) sum += (double)sig[i];
+        ev[s] = sum / (double)(e - b);
+    }
+    __syncthreads();
+
+    // ---- P7: normalise, stats, tail (sig_proc.py:546-605) --------------------------------------------
+    {
+        int has_nan = 0;
+        for (int s = tid; s < nseg; s += BLOCK) has_nan |= (ev[s] != ev[s]);
+        if (__syncthreads_or(has_nan)) {
+            finish(WDX_READ_FAIL_SEGNORM);  // normalize(..., accept_nan=False) raises
+            return;
+        }
+        // np.mean / np.std of the event means (also adapter_event_mean / adapter_event_std)
+        if (tid == 0) sh.mean = np_pairwise_sum_dev(ev, nseg) / (double)nseg;
+        __syncthreads();
+        const double mean = sh.mean;
+        for (int s = tid; s < nseg; s += BLOCK) {
+            const double df = ev[s] - mean;
+            tmp[s] = df * df;
+        }
+        __syncthreads();
+        if (tid == 0) sh.sd = sqrt(np_pairwise_sum_dev(tmp, nseg) / (double)nseg);
+        __syncthreads();
+        const double sd = sh.sd;
+
+        if (P.seg_norm == WDX_NORM_MEAN) {
+            for (int s = tid; s < nseg; s += BLOCK) zz[s] = (ev[s] - mean) / sd;
+        } else if (P.seg_norm == WDX_NORM_MEDIAN) {
+            block_small_median<BLOCK>(ev, nseg, sh, 4);
+            const double m = sh.stat[4];
+            for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(ev[s] - m);
+            block_small_median<BLOCK>(tmp, nseg, sh, 5);
+            const double sc = sh.stat[5];
+            for (int s = tid; s < nseg; s += BLOCK) zz[s] = (ev[s] - m) / sc;
+        } else if (P.seg_norm == WDX_NORM_NONE) {
+            for (int s = tid; s < nseg; s += BLOCK) zz[s] = ev[s];
+        } else {
+            finish(WDX_READ_FAIL_SEGNORM);
+            return;
+        }
+        __syncthreads();
+
+        // stats (sig_proc.py:562-567)
+        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = (double)(cpts[s + 1] - cpts[s]);
+        block_small_median<BLOCK>(tmp, nseg, sh, 0);
+        const double dt_med = sh.stat[0];
+        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(tmp[s] - dt_med);
+        block_small_median<BLOCK>(tmp, nseg, sh, 1);
+        block_small_median<BLOCK>(ev, nseg, sh, 4);
+        const double ev_med = sh.stat[4];
+        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(ev[s] - ev_med);
+        block_small_median<BLOCK>(tmp, nseg, sh, 5);
+
+        if (nseg < K) {
+            finish(WDX_READ_FAIL_UNKNOWN);  // np.pad(int64 dwell, NaN) raises in the reference
+            return;
+        }
+        for (int i = tid; i < K; i += BLOCK) {
+            const int s = nseg - K + i;
+            if (A.fpt) A.fpt[r * K + i] = zz[s];
+            if (A.dwell) A.dwell[r * K + i] = (int64_t)(cpts[s + 1] - cpts[s]);
+        }
+        if (A.stats && tid == 0) {
+            double *o = A.stats + r * 6;
+            o[0] = sh.stat[0];
+            o[1] = sh.stat[1];
+            o[2] = mean;
+            o[3] = sd;
+            o[4] = sh.stat[4];
+            o[5] = sh.stat[5];
+        }
+    }
+    finish(status);
+}
+
+static size_t fp_lds_bytes(int cap) {
+    size_t b = 0;
+    b += (size_t)cap * 8;                   // scores
+    b += (size_t)(kTile + kMaxW) * 8 * 2;   // Mt, Vt (+ state when it fits)
+    b += (size_t)kSegCap * 8 * 3;           // ev, zz, tmp
+    b += sizeof(FpShared);
+    b += (size_t)cap * 4;                   // sig
+    b += (size_t)256 * 4;                   // hist
+    b += (size_t)(kSegCap + 1) * 4;         // cpts
+    if (cap > (int)((kTile + kMaxW) * 16)) b += (size_t)cap;  // dedicated state
+    return (b + 15) & ~(size_t)15;
+}
+
+int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
+                       int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
+                       const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
+                       double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
+                       hipStream_t stream) {
+    if (n_reads == 0) return WDX_SUCCESS;
+    if (p.num_events < 1 || p.num_events > kMaxEvents) {
+        set_error("num_events must be in [1, %d]", kMaxEvents);
+        return p.num_events < 1 ? WDX_ERR_INVALID : WDX_ERR_UNSUPPORTED;
+    }
+    if (p.barcode_num_events < 1 || p.barcode_num_events > kSegCap) {
+        set_error("barcode_num_events must be in [1, %d]", kSegCap);
+        return WDX_ERR_INVALID;
+    }
+    if (p.running_stat_width < 0 || p.running_stat_width > kMaxW) {
+        set_error("running_stat_width must be in [0, %d]", kMaxW);
+        return WDX_ERR_UNSUPPORTED;
+    }
+    if (p.sig_norm == WDX_NORM_MEAN) {
+        set_error("sig_extract.normalization=\"mean\" is not implemented by the HIP engine");
+        return WDX_ERR_UNSUPPORTED;
+    }
+    if (p.padding < 0) {
+        set_error("padding must be >= 0");
+        return WDX_ERR_INVALID;
+    }
+    int64_t cap64 = max_len;
+    if (cap64 > WDX_MAX_ADAPTER_SAMPLES) cap64 = WDX_MAX_ADAPTER_SAMPLES;
+    if (cap64 < 64) cap64 = 64;
+    int cap = (int)((cap64 + 63) / 64 * 64);
+    FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap};
+    const size_t lds = fp_lds_bytes(cap);
+    // two 512-thread workgroups per CU while the carve-up allows it, else one of 1024
+    if (lds <= 80 * 1024) {
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<512>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fingerprint_kernel<512>, dim3((unsigned)n_reads), dim3(512), lds, stream,
+                           A);
+    } else {
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<1024>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fingerprint_kernel<1024>, dim3((unsigned)n_reads), dim3(1024), lds,
+                           stream, A);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+}  // namespace wdx

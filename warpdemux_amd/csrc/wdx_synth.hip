@@ -1,0 +1,118 @@
+// Synthetic RNA004-like adapter signals generated on the device (bench / tests only).
+// Spec "wdx-synth v1" -- see warpdemux_amd/synth.py, which is the bit-identical NumPy statement
+// of the same integer-hash construction (SURVEY.md §8(d) describes the signal model).
+#include "wdx_common.h"
+
+namespace wdx {
+
+constexpr int kPad = 100;
+constexpr int kMaxEv = 140;
+constexpr int kMinEv = 125;
+
+__device__ __forceinline__ uint64_t synth_hash(uint64_t seed, uint64_t read, uint64_t stream,
+                                               uint64_t ctr) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (read + 1ull);
+    z ^= stream * 0xBF58476D1CE4E5B9ull;
+    z += ctr * 0x94D049BB133111EBull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void synth_lengths_kernel(uint64_t seed, int64_t first_read, int64_t n,
+                                     const int32_t *__restrict__ dwell_table,
+                                     int64_t *__restrict__ len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t rid = (uint64_t)(first_read + i);
+    const int n_ev = kMinEv + (int)(synth_hash(seed, rid, 0, 1) % 16ull);
+    int64_t total = 2 * kPad;
+    for (int e = 0; e < n_ev; ++e) total += dwell_table[synth_hash(seed, rid, 1, (uint64_t)e) & 1023ull];
+    len[i] = total;
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(
+    uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes, int32_t n_bc_events,
+    float noise_scale, int32_t spikes, const int32_t *__restrict__ dwell_table,
+    const float *__restrict__ lead, const float *__restrict__ bc, const int64_t *__restrict__ off,
+    float *__restrict__ sig, int32_t *__restrict__ barcode) {
+    __shared__ int bound[kMaxEv + 1];  // bound[e] = first sample of event e (relative to row)
+    __shared__ float level[kMaxEv];
+    const int64_t r = blockIdx.x;
+    const uint64_t rid = (uint64_t)(first_read + r);
+    const int b = (int)(synth_hash(seed, rid, 0, 0) % (uint64_t)n_barcodes);
+    const int n_ev = kMinEv + (int)(synth_hash(seed, rid, 0, 1) % 16ull);
+    if (threadIdx.x < n_ev) {
+        const int e = threadIdx.x;
+        bound[e + 1] = dwell_table[synth_hash(seed, rid, 1, (uint64_t)e) & 1023ull];
+        const int k = n_ev - 1 - e;
+        level[e] = k < n_bc_events ? bc[b * 64 + k] : lead[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = kPad;
+        for (int e = 0; e < n_ev; ++e) {
+            int d = bound[e + 1];
+            bound[e] = acc;
+            acc += d;
+        }
+        bound[n_ev] = acc;
+        if (barcode) barcode[r] = b;
+    }
+    __syncthreads();
+    const int64_t base = off[r];
+    const int len = (int)(off[r + 1] - base);
+    const int ev_end = bound[n_ev];
+    for (int t = threadIdx.x; t < len; t += blockDim.x) {
+        float lv;
+        if (t < kPad) lv = 95.0f;
+        else if (t >= ev_end) lv = 105.0f;
+        else {
+            int lo = 0, hi = n_ev;  // largest e with bound[e] <= t
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (bound[mid] <= t) lo = mid;
+                else hi = mid;
+            }
+            lv = level[lo];
+        }
+        const uint64_t hn = synth_hash(seed, rid, 2, (uint64_t)t);
+        const int isum = (int)(hn & 0xFFFFull) + (int)((hn >> 16) & 0xFFFFull) +
+                         (int)((hn >> 32) & 0xFFFFull) + (int)((hn >> 48) & 0xFFFFull) - 131070;
+        const float noise = (float)isum * noise_scale;
+        float s = lv + noise;
+        if (spikes) {
+            const uint64_t hs = synth_hash(seed, rid, 3, (uint64_t)t);
+            if (hs % 1000ull == 0ull) s = s + (((hs >> 32) & 1ull) ? 60.0f : -60.0f);
+        }
+        sig[base + t] = s;
+    }
+}
+
+int launch_synth_lengths(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,
+                         const int32_t *dwell_table, int64_t *d_len, hipStream_t stream) {
+    (void)n_barcodes;
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(synth_lengths_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       seed, first_read, n, dwell_table, d_len);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+int launch_synth_fill(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,
+                      int32_t n_bc_events, float noise_scale, int32_t spikes,
+                      const int32_t *dwell_table, const float *lead, const float *bc,
+                      const int64_t *off, float *sig, int32_t *barcode, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    if (n_bc_events < 0 || n_bc_events > 64 || n_barcodes < 1) {
+        set_error("synth: n_bc_events must be in [0,64] and n_barcodes >= 1");
+        return WDX_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)n), dim3(256), 0, stream, seed, first_read,
+                       n, n_barcodes, n_bc_events, noise_scale, spikes, dwell_table, lead, bc, off,
+                       sig, barcode);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+}  // namespace wdx

@@ -1,0 +1,213 @@
+"""MI355X batched counterpart of ``warpdemux.sig_proc.detect_results_to_fpt``.
+
+The reference fingerprints one read per Python call (sig_proc.py:394-605) from a loop over the
+minibatch (file_proc.py:418-428).  Here the whole minibatch goes to the HIP engine in one call
+(`detect_results_to_fpt_batch`), and thin shims rebuild per-read `ReadResult` objects with the
+reference's field names and fail-reason strings so the callers' savers see the same records.
+
+Only the non-refinement branch is implemented (``segmentation.consensus_refinement = false`` in
+the shipped RNA004 config); asking for refinement raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+# status code -> ReadResult.fail_reason (reference strings: sig_proc.py:400-407, 440-446, 538-544,
+# 554-560; file_proc.py:224).  Codes 2 and 4 carry the exception text in the reference; the only
+# exception reachable there is mean/mad_normalize's ValueError("Signal contains NaN values.").
+FAIL_REASONS = {
+    0: "",
+    1: None,  # passthrough of detect_results.fail_reason
+    2: "signal normalization failed: Signal contains NaN values.",
+    3: "event segmentation failed",
+    4: "segment normalization failed: Signal contains NaN values.",
+    5: "unknown",
+}
+
+
+@dataclass
+class SegParams:
+    """Hot-path knobs of SigProcConfig (config/sig_proc.py:16-70); defaults = shipped
+    rna004_130bps@v1.0.toml, outlier threshold = ADAPTed's core.sig_norm_outlier_thresh default."""
+
+    padding: int = 100
+    sig_norm: str = "none"
+    outlier_thresh: float = 5.0
+    min_obs_per_base: int = 6
+    running_stat_width: int = 12
+    num_events: int = 110
+    accept_less_cpts: bool = False
+    seg_norm: str = "mean"
+    barcode_num_events: int = 25
+
+    @classmethod
+    def from_spc(cls, spc) -> "SegParams":
+        """From a reference-style SigProcConfig (attribute access as in sig_proc.py:414-534)."""
+        seg = spc.segmentation
+        if getattr(seg, "consensus_refinement", False):
+            raise NotImplementedError("consensus_refinement is not implemented by the HIP engine")
+        k = seg.barcode_num_events
+        if not isinstance(k, (int, np.integer)):
+            raise ValueError("barcode_num_events must be an int outside consensus refinement mode")
+        return cls(
+            padding=int(spc.sig_extract.padding),
+            sig_norm=str(spc.sig_extract.normalization),
+            outlier_thresh=float(spc.core.sig_norm_outlier_thresh),
+            min_obs_per_base=int(seg.min_obs_per_base),
+            running_stat_width=int(seg.running_stat_width),
+            num_events=int(seg.num_events),
+            accept_less_cpts=bool(seg.accept_less_cpts),
+            seg_norm=str(seg.normalization),
+            barcode_num_events=int(k),
+        )
+
+    def to_c(self) -> _lib.SegParamsC:
+        for name in (self.sig_norm, self.seg_norm):
+            if name not in _lib.NORM_CODES:
+                msg = f"Normalization method {name} not recognized."
+                raise ValueError(msg)
+        return _lib.SegParamsC(
+            self.padding, _lib.NORM_CODES[self.sig_norm], self.outlier_thresh, self.min_obs_per_base,
+            self.running_stat_width, self.num_events, int(self.accept_less_cpts),
+            _lib.NORM_CODES[self.seg_norm], self.barcode_num_events,
+        )
+
+
+@dataclass
+class DetectResults:
+    """The four fields of ADAPTed's DetectResults the hot path reads (sig_proc.py:400-418)."""
+
+    success: bool = True
+    fail_reason: str = ""
+    adapter_start: Optional[int] = None
+    adapter_end: Optional[int] = None
+
+
+@dataclass
+class ReadResult:
+    """Same fields as warpdemux.sig_proc.ReadResult (sig_proc.py:26-62)."""
+
+    read_id: Optional[str] = None
+    success: bool = True
+    fail_reason: str = ""
+    detect_results: Any = None
+    barcode_fpt: Optional[np.ndarray] = None
+    dwell_times: Optional[np.ndarray] = None
+    adapter_dt_med: Optional[float] = None
+    adapter_dt_mad: Optional[float] = None
+    adapter_event_mean: Optional[float] = None
+    adapter_event_std: Optional[float] = None
+    adapter_event_med: Optional[float] = None
+    adapter_event_mad: Optional[float] = None
+    seg_cons_query_start: Optional[int] = None
+    seg_cons_query_end: Optional[int] = None
+    sig_barcode_start: Optional[int] = None
+
+    def to_summary_dict(self) -> Dict[str, Any]:
+        return {
+            "read_id": self.read_id,
+            "success": self.success,
+            "fail_reason": self.fail_reason,
+            "adapter_dt_med": self.adapter_dt_med,
+            "adapter_dt_mad": self.adapter_dt_mad,
+            "adapter_event_mean": self.adapter_event_mean,
+            "adapter_event_std": self.adapter_event_std,
+            "adapter_event_med": self.adapter_event_med,
+            "adapter_event_mad": self.adapter_event_mad,
+            "seg_cons_query_start": self.seg_cons_query_start,
+            "seg_cons_query_end": self.seg_cons_query_end,
+            "sig_barcode_start": self.sig_barcode_start,
+        }
+
+    def set_read_id(self, read_id: str):
+        self.read_id = read_id
+
+
+@dataclass
+class FingerprintBatch:
+    """Struct-of-arrays result of one minibatch."""
+
+    fpt: np.ndarray      # (n, K) float64, NaN rows for failed reads
+    dwell: np.ndarray    # (n, K) int64
+    stats: np.ndarray    # (n, 6) float64: dt_med, dt_mad, event_mean, event_std, event_med, event_mad
+    status: np.ndarray   # (n,) int32, WDX_READ_*
+
+    @property
+    def success(self) -> np.ndarray:
+        return self.status == 0
+
+
+def fingerprint_batch(signals, adapter_start, adapter_end, params: SegParams, success=None, device=None) -> FingerprintBatch:
+    """Fingerprint a (n_reads, stride) float32 minibatch (file_proc.py:244-260 layout, NaN tail)."""
+    sig = np.asarray(signals)
+    if sig.ndim != 2:
+        raise ValueError("signals must be a 2-D (n_reads, stride) array")
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    n, stride = sig.shape
+    a_s = np.ascontiguousarray(adapter_start, dtype=np.int32)
+    a_e = np.ascontiguousarray(adapter_end, dtype=np.int32)
+    if a_s.shape != (n,) or a_e.shape != (n,):
+        raise ValueError("adapter_start/adapter_end must have one entry per read")
+    ok = None if success is None else np.ascontiguousarray(success, dtype=np.uint8)
+    pc = params.to_c()
+    K = params.barcode_num_events
+    fpt = np.empty((n, K), dtype=np.float64)
+    dwell = np.empty((n, K), dtype=np.int64)
+    stats = np.empty((n, 6), dtype=np.float64)
+    status = np.empty(n, dtype=np.int32)
+    ctx = _lib.default_context(device)
+    L = _lib.load()
+    _lib.check(
+        L.wdx_fingerprint_batch(
+            ctx.handle, _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e), _lib.ptr(ok),
+            C.byref(pc), _lib.ptr(fpt), _lib.ptr(dwell), _lib.ptr(stats), _lib.ptr(status),
+        )
+    )
+    return FingerprintBatch(fpt, dwell, stats, status)
+
+
+def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequence, read_ids: Optional[Sequence[str]] = None, device=None) -> List[ReadResult]:
+    """Batched `detect_results_to_fpt`: one ReadResult per row, identical fields to the reference's
+    per-read call (sig_proc.py:590-605) plus the `barcode_fpt_wrapper` read-id (file_proc.py:216)."""
+    params = SegParams.from_spc(spc)
+    n = len(detect_results)
+    ok = np.array([bool(d.success) for d in detect_results], dtype=np.uint8)
+    a_s = np.array([d.adapter_start if (d.success and d.adapter_start is not None) else 0 for d in detect_results], dtype=np.int32)
+    a_e = np.array([d.adapter_end if (d.success and d.adapter_end is not None) else 0 for d in detect_results], dtype=np.int32)
+    fb = fingerprint_batch(calibrated_signals, a_s, a_e, params, success=ok, device=device)
+    out = []
+    for i in range(n):
+        st = int(fb.status[i])
+        rid = None if read_ids is None else read_ids[i]
+        if st == 0:
+            s = fb.stats[i]
+            out.append(ReadResult(
+                read_id=rid, success=True, fail_reason="", detect_results=detect_results[i],
+                barcode_fpt=fb.fpt[i].copy(), dwell_times=fb.dwell[i].copy(),
+                adapter_dt_med=float(s[0]), adapter_dt_mad=float(s[1]), adapter_event_mean=float(s[2]),
+                adapter_event_std=float(s[3]), adapter_event_med=float(s[4]), adapter_event_mad=float(s[5]),
+            ))
+        elif st == 5:
+            # barcode_fpt_wrapper's except-branch builds a bare record (file_proc.py:220-224)
+            out.append(ReadResult(read_id=rid, success=False, fail_reason="unknown"))
+        else:
+            reason = detect_results[i].fail_reason if st == 1 else FAIL_REASONS[st]
+            out.append(ReadResult(
+                read_id=rid, success=False, fail_reason=reason, detect_results=detect_results[i],
+                barcode_fpt=np.array([]), dwell_times=np.array([]),
+            ))
+    return out
+
+
+def detect_results_to_fpt(calibrated_signal, spc, detect_results, consensus_query=np.array([])) -> ReadResult:
+    """Per-read signature of the reference (sig_proc.py:394-399); a batch of one."""
+    if np.asarray(consensus_query).size:
+        raise NotImplementedError("consensus refinement is not implemented by the HIP engine")
+    sig = np.asarray(calibrated_signal, dtype=np.float32).reshape(1, -1)
+    return detect_results_to_fpt_batch(sig, spc, [detect_results])[0]
