@@ -130,7 +130,7 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                         const uint8_t *d_ok, const wdx_seg_params *p, double *d_fpt,
                         int64_t *d_dwell, double *d_stats, int32_t *d_status, void *stream);
 
-#define WDX_MAX_ADAPTER_SAMPLES 12288
+#define WDX_MAX_ADAPTER_SAMPLES 11200
 
 /* ---- fused path: raw adapter rows -> fingerprint -> DTW to the resident refs -> call ------ */
 

@@ -60,6 +60,31 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (soname libamdhip64.so.7) but request it as "libamdhip64.so", so if libwdx_hip.so pulled in
+    /opt/rocm's copy first a later `import torch` would load a second runtime and lose the GPU.
+    Loading torch's copy first (when torch is installed) makes both resolve to the same object;
+    without torch the RUNPATH of libwdx_hip.so finds /opt/rocm.  $WDX_HIP_RUNTIME overrides."""
+    cand = os.environ.get("WDX_HIP_RUNTIME")
+    if not cand:
+        try:
+            import importlib.util
+
+            spec = importlib.util.find_spec("torch")
+            if spec and spec.origin:
+                c = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+                if os.path.exists(c):
+                    cand = c
+        except Exception:
+            cand = None
+    if cand:
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen the engine; raises if it has not been built."""
     global _lib
@@ -71,6 +96,7 @@ def load():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C warpdemux_amd/csrc` (there is no CPU fallback)"
             )
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
         P = C.POINTER

@@ -726,6 +726,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
              p,     d_fpt,     d_dwell,   d_stats, d_status, cap};
     const size_t lds = fp_lds_bytes(cap);
+    if (lds > 160 * 1024) {
+        set_error("fingerprint LDS carve-up (%zu B) exceeds 160 KiB", lds);
+        return WDX_ERR_INVALID;
+    }
+    (void)hipGetLastError();  // do not inherit a stale error from an earlier failed call
     // two 512-thread workgroups per CU while the carve-up allows it, else one of 1024
     if (lds <= 80 * 1024) {
         WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<512>,
