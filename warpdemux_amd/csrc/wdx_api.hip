@@ -378,6 +378,23 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                               (hipStream_t)stream);
 }
 
+int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                                int64_t stride, int64_t max_len, int64_t n_reads,
+                                const int32_t *d_a_start, const int32_t *d_a_end,
+                                const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
+                                int64_t prof_reads, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!p || !d_prof || !d_status) {
+        set_error("fingerprint_profile_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
+                              nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
+                              d_prof, prof_reads);
+}
+
 int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
                           const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
                           const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,

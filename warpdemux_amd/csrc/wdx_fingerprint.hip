@@ -46,7 +46,10 @@ struct FpArgs {
     int64_t *dwell;
     double *stats;
     int32_t *status;
-    int cap;  // LDS capacity in samples
+    int cap;             // LDS capacity in samples
+    int64_t block_base;  // first read of this launch (grid.x * block.x must stay below 2^32)
+    long long *prof;     // diagnostic build only: 16 cycle stamps per read
+    int64_t prof_reads;
 };
 
 struct alignas(8) FpShared {
@@ -310,11 +313,22 @@ __device__ void block_small_median(const double *a, int n, FpShared &sh, int slo
 
 // ---- the kernel -----------------------------------------------------------------------------------
 
-template <int BLOCK>
+// PROF = diagnostic instantiation with s_memtime stamps between phases (never used by the product
+// entry points; see wdx_fingerprint_profile_dev).
+#define WDX_STAMP(k)                                                                        \
+    do {                                                                                    \
+        if (PROF) {                                                                         \
+            __syncthreads();                                                                \
+            if (tid == 0 && r < A.prof_reads)                                               \
+                A.prof[r * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime();             \
+        }                                                                                   \
+    } while (0)
+
+template <int BLOCK, bool PROF>
 __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;
+    const int64_t r = A.block_base + blockIdx.x;
     const wdx_seg_params &P = A.p;
     const int K = P.barcode_num_events;
     const int E = P.num_events;
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
         return;
     }
 
+    WDX_STAMP(0);
     // ---- A0 extract_adapter (sig_proc.py:382-391) --------------------------------------------------
     const int64_t row_off = A.row_off ? A.row_off[r] : r * A.stride;
     const int64_t row_len = A.row_len ? (int64_t)A.row_len[r]
@@ -378,6 +393,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
     }
     __syncthreads();
 
+    WDX_STAMP(1);
     // ---- P1: MAD outlier clip (sig_proc.py:421-431), float32 ---------------------------------------
     {
         const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
@@ -401,6 +417,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
         __syncthreads();
     }
 
+    WDX_STAMP(2);
     // ---- A2: optional signal normalisation (sig_proc.py:433-446); "none" in every shipped config ----
     if (n > 0 && P.sig_norm == WDX_NORM_MEDIAN) {
         const float shift = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
@@ -459,6 +476,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
         }
     }
 
+    WDX_STAMP(3);
     // ---- P3: find_peaks(scores, distance=d_eff) ----------------------------------
     for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
     __syncthreads();
@@ -471,6 +489,8 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
         }
     }
     __syncthreads();
+    WDX_STAMP(4);
+    int nms_iters = 0;
     {
         // greedy suppression by priority == fixed point of: a peak is KEPT once every higher-priority
         // peak closer than d_eff is DROPPED, and DROPPED as soon as one of them is KEPT.
@@ -496,9 +516,11 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
                 else if (!wait) state[i] = ST_KEPT;
                 else pending = 1;
             }
+            ++nms_iters;
             if (!__syncthreads_or(pending)) break;
         }
     }
+    WDX_STAMP(5);
 
     // ---- P4: keep the E highest peaks (sig_proc.py:185-188) -----------------------------------------
     int nsel;
@@ -572,6 +594,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
         __syncthreads();
     }
 
+    WDX_STAMP(6);
     // ---- P5: boundaries 0, peaks+W (ascending), n  (sig_proc.py:188-196) -----------------------------
     {
         const int chunk = (ns + BLOCK - 1) / BLOCK;
@@ -600,6 +623,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
     }
     const int nseg = nsel + 1;
 
+    WDX_STAMP(7);
     // ---- P6: event means (_c_segmentation.pyx:41-53), sequential float64 sums ------------------------
     for (int s = tid; s < nseg; s += BLOCK) {
         const int b = cpts[s], e = cpts[s + 1];
@@ -609,6 +633,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
     }
     __syncthreads();
 
+    WDX_STAMP(8);
     // ---- P7: normalise, stats, tail (sig_proc.py:546-605) --------------------------------------------
     {
         int has_nan = 0;
@@ -677,6 +702,12 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
             o[5] = sh.stat[5];
         }
     }
+    WDX_STAMP(9);
+    if (PROF && tid == 0 && r < A.prof_reads) {
+        A.prof[r * 16 + 10] = nms_iters;
+        A.prof[r * 16 + 11] = n;
+        A.prof[r * 16 + 12] = ns;
+    }
     finish(status);
 }
 
@@ -693,11 +724,27 @@ static size_t fp_lds_bytes(int cap) {
     return (b + 15) & ~(size_t)15;
 }
 
+template <int BLOCK, bool PROF>
+static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream) {
+    WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<BLOCK, PROF>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // HIP drops work when grid.x * block.x reaches 2^32: launch in slices of 2^21 reads
+    const int64_t slice = 1 << 21;
+    for (int64_t base = 0; base < A.n_reads; base += slice) {
+        const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
+        A.block_base = base;
+        hipLaunchKernelGGL((fingerprint_kernel<BLOCK, PROF>), dim3((unsigned)n), dim3(BLOCK), lds,
+                           stream, A);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
-                       hipStream_t stream) {
+                       hipStream_t stream, long long *d_prof, int64_t prof_reads) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (p.num_events < 1 || p.num_events > kMaxEvents) {
         set_error("num_events must be in [1, %d]", kMaxEvents);
@@ -724,7 +771,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads};
     const size_t lds = fp_lds_bytes(cap);
     if (lds > 160 * 1024) {
         set_error("fingerprint LDS carve-up (%zu B) exceeds 160 KiB", lds);
@@ -732,19 +779,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     }
     (void)hipGetLastError();  // do not inherit a stale error from an earlier failed call
     // two 512-thread workgroups per CU while the carve-up allows it, else one of 1024
-    if (lds <= 80 * 1024) {
-        WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<512>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fingerprint_kernel<512>, dim3((unsigned)n_reads), dim3(512), lds, stream,
-                           A);
-    } else {
-        WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<1024>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fingerprint_kernel<1024>, dim3((unsigned)n_reads), dim3(1024), lds,
-                           stream, A);
-    }
-    WDX_HIP_TRY(hipGetLastError());
-    return WDX_SUCCESS;
+    const bool small = lds <= 80 * 1024;
+    if (d_prof) return small ? launch_fp_chunks<512, true>(A, lds, stream)
+                             : launch_fp_chunks<1024, true>(A, lds, stream);
+    return small ? launch_fp_chunks<512, false>(A, lds, stream)
+                 : launch_fp_chunks<1024, false>(A, lds, stream);
 }
 
 }  // namespace wdx

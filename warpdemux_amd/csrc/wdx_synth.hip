@@ -35,10 +35,10 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(
     uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes, int32_t n_bc_events,
     float noise_scale, int32_t spikes, const int32_t *__restrict__ dwell_table,
     const float *__restrict__ lead, const float *__restrict__ bc, const int64_t *__restrict__ off,
-    float *__restrict__ sig, int32_t *__restrict__ barcode) {
+    float *__restrict__ sig, int32_t *__restrict__ barcode, int64_t block_base) {
     __shared__ int bound[kMaxEv + 1];  // bound[e] = first sample of event e (relative to row)
     __shared__ float level[kMaxEv];
-    const int64_t r = blockIdx.x;
+    const int64_t r = block_base + blockIdx.x;
     const uint64_t rid = (uint64_t)(first_read + r);
     const int b = (int)(synth_hash(seed, rid, 0, 0) % (uint64_t)n_barcodes);
     const int n_ev = kMinEv + (int)(synth_hash(seed, rid, 0, 1) % 16ull);
@@ -108,9 +108,13 @@ int launch_synth_fill(uint64_t seed, int64_t first_read, int64_t n, int32_t n_ba
         set_error("synth: n_bc_events must be in [0,64] and n_barcodes >= 1");
         return WDX_ERR_INVALID;
     }
-    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)n), dim3(256), 0, stream, seed, first_read,
-                       n, n_barcodes, n_bc_events, noise_scale, spikes, dwell_table, lead, bc, off,
-                       sig, barcode);
+    const int64_t slice = 1 << 22;  // grid.x * block.x must stay below 2^32
+    for (int64_t base = 0; base < n; base += slice) {
+        const int64_t m = n - base < slice ? n - base : slice;
+        hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)m), dim3(256), 0, stream, seed,
+                           first_read, n, n_barcodes, n_bc_events, noise_scale, spikes, dwell_table,
+                           lead, bc, off, sig, barcode, base);
+    }
     WDX_HIP_TRY(hipGetLastError());
     return WDX_SUCCESS;
 }
