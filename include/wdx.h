@@ -160,14 +160,16 @@ int wdx_kernel_timing(wdx_ctx *ctx, int enable);
 int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
 int wdx_kernel_time_reset(wdx_ctx *ctx);
 /* Diagnostic build of the fingerprint kernel with s_memtime stamps between its phases:
- * d_prof receives 16 int64 per read for the first prof_reads reads (slots 0..9 = shader-clock
+ * d_prof receives 32 int64 per read for the first prof_reads reads (slots 0..9 = shader-clock
  * stamps at the phase boundaries P0..P7, 10 = suppression iterations, 11 = adapter samples,
- * 12 = score positions).  Outputs other than d_status are discarded.  Never on the product path. */
+ * 12 = score positions / peaks).  fast_path selects the 256-thread fast kernel (+ slow-path list;
+ * slot 15 of read 0 then holds the number of reads it declined) or the one-kernel exact path.
+ * Outputs other than d_status are discarded.  Never on the product path. */
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                                 int64_t stride, int64_t max_len, int64_t n_reads,
                                 const int32_t *d_a_start, const int32_t *d_a_end,
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
-                                int64_t prof_reads, void *stream);
+                                int64_t prof_reads, int32_t fast_path, void *stream);
 
 /* ---- synthetic input generator (bench / tests; spec "wdx-synth v1", warpdemux_amd/synth.py) */
 

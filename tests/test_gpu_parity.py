@@ -214,6 +214,35 @@ def test_fingerprint_minibatch_vs_oracle(K):
     assert np.isnan(fb.fpt[~good]).all()
 
 
+def test_fast_and_slow_paths_agree(monkeypatch):
+    """The 256-thread fast kernel and the exact slow path (forced with WDX_FORCE_SLOW) must give
+    identical bits, with and without the optional stats, for every segmentation normalisation."""
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 77_000, 1200, 9000)
+    rng = np.random.default_rng(1)
+    mb[3, 1500:1510] = np.nan                     # NaN -> slow path inside the fast launch
+    mb[4, 200:4000] = np.round(mb[4, 200:4000])   # integer-valued samples: exact score ties/plateaus
+    mb[5, :] = np.float32(80.0)                   # constant
+    a_e[6] = a_s[6] + 1100                        # shrunk window width -> slow path
+    for seg_norm in ("mean", "median", "none"):
+        for K in (25, 110):
+            ph = sig_proc.SegParams(barcode_num_events=K, seg_norm=seg_norm)
+            po = orc.SegParams(barcode_num_events=K, seg_norm=seg_norm)
+            monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+            fast = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+            monkeypatch.setenv("WDX_FORCE_SLOW", "1")
+            slow = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+            monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+            assert np.array_equal(fast.status, slow.status)
+            assert _same(fast.fpt, slow.fpt) and _same(fast.dwell, slow.dwell) and _same(fast.stats, slow.stats)
+            fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
+            assert np.array_equal(fast.status, status)
+            good = status == 0
+            assert good.sum() > 1150
+            assert _same(fast.fpt[good], fpt[good]) and _same(fast.dwell[good], dwell[good])
+            assert _same(fast.stats[good], stats[good])
+
+
 def test_fingerprint_long_rows_and_capacity():
     """adapter windows up to the on-chip capacity (1024-thread / one-workgroup-per-CU carve-up)"""
     rng = np.random.default_rng(12)

@@ -15,26 +15,49 @@ from warpdemux_amd import _lib, sig_proc, synth  # noqa: E402
 from warpdemux_amd.engine import DemuxEngine, _dp  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+fast = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 K = 110
 spec = synth.SynthSpec(n_barcodes=10)
 eng = DemuxEngine(np.zeros((10, K)), 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
 sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, n)
 status = torch.empty(n, dtype=torch.int32, device="cuda")
-prof = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+prof = torch.zeros((n, 32), dtype=torch.int64, device="cuda")
 pc = eng.params.to_c()
 for _ in range(2):
     _lib.check(eng.L.wdx_fingerprint_profile_dev(eng.ctx.handle, _dp(sig), _dp(off), 0, max_len, n, _dp(a_s), _dp(a_e),
-                                                 C.byref(pc), _dp(status), _dp(prof), n, None))
+                                                 C.byref(pc), _dp(status), _dp(prof), n, fast, None))
 torch.cuda.synchronize()
 p = prof.cpu().numpy()
 ok = status.cpu().numpy() == 0
-p = p[ok]
-names = ["P0 load", "P1 median+clip", "A2+shrink", "P2 t-score", "P3a local maxima", "P3b suppression", "P4 top-E",
-         "P5 boundaries", "P6 event means", "P7 normalise/stats"]
+declined = int(p[0, 15]) if fast else 0
+if fast:
+    dec = p[p[:, 9] == 0]
+    print("decline reasons (0 gate,1 NaN,2 inexact,3 plateau/cap,4 nbr,5 kept cap,6 tie):", np.bincount(dec[:, 13].astype(int), minlength=7).tolist())
+if fast:
+    names = ["P0 load", "P1a median", "P1b MAD+clip", "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E",
+             "P5 boundaries", "P6 event means", "P7 normalise"]
+    p = p[p[:, 9] != 0]   # reads the fast kernel finished (declined reads carry no end stamp)
+else:
+    names = ["P0 load", "P1 median+clip", "P2 t-score", "P3a local maxima", "P3b suppression", "P4 top-E",
+             "P5 boundaries", "P6 event means", "P7 normalise/stats"]
 d = np.diff(p[:, :10], axis=1)
 tot = p[:, 9] - p[:, 0]
+print(f"fast={fast} declined_to_slow={declined} profiled={p.shape[0]}")
 print(f"reads {ok.sum()}  max_len {max_len}  median total cycles/read {np.median(tot):.0f}  mean {tot.mean():.0f}")
 for i in range(9):
     print(f"  {names[i]:22s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}  share {d[:, i].sum() / tot.sum() * 100:5.1f}%")
 print("  suppression iterations: median %d  p99 %d  max %d" % (np.median(p[:, 10]), np.percentile(p[:, 10], 99), p[:, 10].max()))
 print("  n samples median %d, score positions median %d" % (np.median(p[:, 11]), np.median(p[:, 12])))
+
+if fast:
+    q = p[:, 16:23]
+    lab = ["minmax", "zero+hist", "scan+locate", "gather", "rank", "evenfix"]
+    base = p[:, 1]
+    prev = base
+    print("  median-1 internals (cycles, median over reads):")
+    for i, name in enumerate(lab):
+        cur = q[:, i]
+        okm = cur > 0
+        print(f"    {name:12s} {np.median((cur - prev)[okm]):8.0f}   (n={okm.sum()})")
+        prev = np.where(okm, cur, prev)
+    print("    small-list size median %d p99 %d" % (np.median(q[:, 6]), np.percentile(q[:, 6], 99)))

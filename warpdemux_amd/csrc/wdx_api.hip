@@ -70,10 +70,11 @@ struct wdx_ctx {
     DtwRefs refs;
     Buffer refs_pad, refs_T, refs_nan;
     // host-buffer call workspaces
-    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch;
+    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[kNumTimed];
+    std::vector<int64_t> pending_launches[kNumTimed];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double acc_ms[kNumTimed] = {0, 0, 0, 0};
     int64_t launches[kNumTimed] = {0, 0, 0, 0};
@@ -86,6 +87,7 @@ struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
     int id;
     hipStream_t s;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    int64_t n_launches = 0;  // kernel launches bracketed by this event pair (0 -> counted as 1)
     Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
         if (!c->timing) return;
         if (!c->pool.empty()) {
@@ -103,6 +105,7 @@ struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
         if (!ev.first) return;
         (void)hipEventRecord(ev.second, s);
         c->pending[id].push_back(ev);
+        c->pending_launches[id].push_back(n_launches > 0 ? n_launches : 1);
     }
 };
 
@@ -286,7 +289,7 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws})
         b->release();
     for (int k = 0; k < kNumTimed; ++k)
         for (auto &e : ctx->pending[k]) {
@@ -372,17 +375,18 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     Timed t(ctx, WDX_K_FINGERPRINT, (hipStream_t)stream);
     return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                               d_a_end, d_ok, *p, d_fpt, d_dwell, d_stats, d_status,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, ctx->fp_ws.p, &t.n_launches);
 }
 
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                                 int64_t stride, int64_t max_len, int64_t n_reads,
                                 const int32_t *d_a_start, const int32_t *d_a_end,
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
-                                int64_t prof_reads, void *stream) {
+                                int64_t prof_reads, int32_t fast_path, void *stream) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!p || !d_prof || !d_status) {
@@ -390,9 +394,19 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
-    return launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
-                              nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
-                              d_prof, prof_reads);
+    if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    rc = launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
+                            nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
+                            fast_path ? ctx->fp_ws.p : nullptr, nullptr, d_prof, prof_reads);
+    if (rc == WDX_SUCCESS && fast_path && prof_reads > 0) {
+        // slot 15 of read 0 <- number of reads the fast kernel handed to the slow path
+        WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        unsigned cnt = 0;
+        WDX_HIP_TRY(hipMemcpy(&cnt, ctx->fp_ws.p, 4, hipMemcpyDeviceToHost));
+        long long v = cnt;
+        WDX_HIP_TRY(hipMemcpy(d_prof + 15, &v, 8, hipMemcpyHostToDevice));  // row 0, slot 15 of 32
+    }
+    return rc;
 }
 
 int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
@@ -432,6 +446,7 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
     if ((rc = ctx->out1.ensure((size_t)(n_reads * K) * 8))) return rc;
     if ((rc = ctx->out2.ensure((size_t)n_reads * 6 * 8))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, sig, sb, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
@@ -443,7 +458,8 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
                                      (const int32_t *)ctx->in2.p,
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p,
                                      (double *)ctx->out0.p, (int64_t *)ctx->out1.p,
-                                     (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s)))
+                                     (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p,
+                                     &t.n_launches)))
             return rc;
     }
     WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
@@ -457,8 +473,8 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
 int64_t wdx_demux_workspace_bytes(int64_t n_reads, int32_t K) {
     if (n_reads < 0 || K < 1) return 0;
     const int64_t ld = round_up(n_reads > 0 ? n_reads : 1, 64);
-    // [fpt (n,K) f64][fptT (K,ld) f64][nan flags ld]
-    return n_reads * K * 8 + (int64_t)K * ld * 8 + ld + 256;
+    // [fpt (n,K) f64][fptT (K,ld) f64][nan flags ld][slow-path list]
+    return n_reads * K * 8 + (int64_t)K * ld * 8 + ld + 256 + fingerprint_workspace_bytes(n_reads);
 }
 
 int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
@@ -497,10 +513,12 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
     double *fpt = d_fpt ? d_fpt : (double *)w;
     double *fptT = (double *)(w + n_reads * K * 8);
     uint8_t *flags = (uint8_t *)(w + n_reads * K * 8 + K * ld * 8);
+    void *fp_ws = w + ((n_reads * K * 8 + K * ld * 8 + ld + 255) / 256) * 256;
     {
         Timed t(ctx, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
-                                     d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s)))
+                                     d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s, fp_ws,
+                                     &t.n_launches)))
             return rc;
     }
     {
@@ -533,15 +551,17 @@ int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
-    for (auto &e : ctx->pending[kernel_id]) {
+    for (size_t i = 0; i < ctx->pending[kernel_id].size(); ++i) {
+        auto &e = ctx->pending[kernel_id][i];
         WDX_HIP_TRY(hipEventSynchronize(e.second));
         float ms = 0;
         WDX_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
         ctx->acc_ms[kernel_id] += ms;
-        ctx->launches[kernel_id] += 1;
+        ctx->launches[kernel_id] += ctx->pending_launches[kernel_id][i];
         ctx->pool.push_back(e);
     }
     ctx->pending[kernel_id].clear();
+    ctx->pending_launches[kernel_id].clear();
     if (total_ms) *total_ms = ctx->acc_ms[kernel_id];
     if (launches) *launches = ctx->launches[kernel_id];
     return WDX_SUCCESS;
@@ -557,6 +577,7 @@ int wdx_kernel_time_reset(wdx_ctx *ctx) {
             ctx->pool.push_back(e);
         }
         ctx->pending[k].clear();
+        ctx->pending_launches[k].clear();
         ctx->acc_ms[k] = 0;
         ctx->launches[k] = 0;
     }

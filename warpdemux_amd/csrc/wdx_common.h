@@ -64,7 +64,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
-                       hipStream_t stream, long long *d_prof = nullptr, int64_t prof_reads = 0);
+                       hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
+                       int64_t *n_launches = nullptr, long long *d_prof = nullptr,
+                       int64_t prof_reads = 0);
+int64_t fingerprint_workspace_bytes(int64_t n_reads);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------
 int launch_synth_lengths(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,

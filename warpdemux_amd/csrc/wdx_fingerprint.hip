@@ -23,6 +23,8 @@
 //   P7 normalise+stats numpy pairwise mean/std, medians by rank counting, tail-K extract (A6)
 #include "wdx_common.h"
 
+#include <stdlib.h>
+
 namespace wdx {
 
 constexpr int kMaxW = 64;        // cap on running_stat_width
@@ -320,15 +322,13 @@ __device__ void block_small_median(const double *a, int n, FpShared &sh, int slo
         if (PROF) {                                                                         \
             __syncthreads();                                                                \
             if (tid == 0 && r < A.prof_reads)                                               \
-                A.prof[r * 16 + (k)] = (long long)__builtin_amdgcn_s_memtime();             \
+                A.prof[r * 32 + (k)] = (long long)__builtin_amdgcn_s_memtime();             \
         }                                                                                   \
     } while (0)
 
 template <int BLOCK, bool PROF>
-__global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char *smem) {
     const int tid = threadIdx.x;
-    const int64_t r = A.block_base + blockIdx.x;
     const wdx_seg_params &P = A.p;
     const int K = P.barcode_num_events;
     const int E = P.num_events;
@@ -704,12 +704,33 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
     }
     WDX_STAMP(9);
     if (PROF && tid == 0 && r < A.prof_reads) {
-        A.prof[r * 16 + 10] = nms_iters;
-        A.prof[r * 16 + 11] = n;
-        A.prof[r * 16 + 12] = ns;
+        A.prof[r * 32 + 10] = nms_iters;
+        A.prof[r * 32 + 11] = n;
+        A.prof[r * 32 + 12] = ns;
     }
     finish(status);
 }
+
+// one workgroup per read
+template <int BLOCK, bool PROF>
+__global__ __launch_bounds__(BLOCK) void fingerprint_kernel(FpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fp_process_read<BLOCK, PROF>(A, A.block_base + blockIdx.x, smem);
+}
+
+// exact slow path: the reads the fast kernel declined (list built with atomics), grid-stride
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fingerprint_list_kernel(FpArgs A, const unsigned *count,
+                                                                 const int32_t *list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned n = *count;
+    for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
+        __syncthreads();
+        fp_process_read<BLOCK, false>(A, (int64_t)list[k], smem);
+    }
+}
+
+#include "wdx_fingerprint_fast.inc"
 
 static size_t fp_lds_bytes(int cap) {
     size_t b = 0;
@@ -725,7 +746,7 @@ static size_t fp_lds_bytes(int cap) {
 }
 
 template <int BLOCK, bool PROF>
-static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream) {
+static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream, int64_t *n_launches) {
     WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<BLOCK, PROF>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // HIP drops work when grid.x * block.x reaches 2^32: launch in slices of 2^21 reads
@@ -735,17 +756,37 @@ static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream) {
         A.block_base = base;
         hipLaunchKernelGGL((fingerprint_kernel<BLOCK, PROF>), dim3((unsigned)n), dim3(BLOCK), lds,
                            stream, A);
+        if (n_launches) ++*n_launches;
     }
     WDX_HIP_TRY(hipGetLastError());
     return WDX_SUCCESS;
 }
 
+template <int BLOCK>
+static int launch_fp_list(const FpArgs &A, size_t lds, const unsigned *count, const int32_t *list,
+                          hipStream_t stream) {
+    WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_list_kernel<BLOCK>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t grid = A.n_reads < 2048 ? A.n_reads : 2048;
+    hipLaunchKernelGGL((fingerprint_list_kernel<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), lds, stream,
+                       A, count, list);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 4 * (n_reads > 0 ? n_reads : 0); }
+
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
-                       hipStream_t stream, long long *d_prof, int64_t prof_reads) {
+                       hipStream_t stream, void *d_ws, int64_t *n_launches, long long *d_prof,
+                       int64_t prof_reads) {
     if (n_reads == 0) return WDX_SUCCESS;
+    if (n_reads > 0x7fffffffLL) {
+        set_error("at most 2^31-1 reads per call");
+        return WDX_ERR_INVALID;
+    }
     if (p.num_events < 1 || p.num_events > kMaxEvents) {
         set_error("num_events must be in [1, %d]", kMaxEvents);
         return p.num_events < 1 ? WDX_ERR_INVALID : WDX_ERR_UNSUPPORTED;
@@ -778,12 +819,50 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         return WDX_ERR_INVALID;
     }
     (void)hipGetLastError();  // do not inherit a stale error from an earlier failed call
-    // two 512-thread workgroups per CU while the carve-up allows it, else one of 1024
     const bool small = lds <= 80 * 1024;
-    if (d_prof) return small ? launch_fp_chunks<512, true>(A, lds, stream)
-                             : launch_fp_chunks<1024, true>(A, lds, stream);
-    return small ? launch_fp_chunks<512, false>(A, lds, stream)
-                 : launch_fp_chunks<1024, false>(A, lds, stream);
+    if (d_prof && !d_ws) return small ? launch_fp_chunks<512, true>(A, lds, stream, n_launches)
+                                      : launch_fp_chunks<1024, true>(A, lds, stream, n_launches);
+
+    // fast path for the common case + exact slow path for whatever it declines
+    const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
+                         p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
+                         p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
+                         !getenv("WDX_FORCE_SLOW");
+    if (fast_ok) {
+        // samples per thread: the smallest instantiation that holds the longest adapter window,
+        // capped at 24 (longer reads take the slow path)
+        const int npt = cap <= 16 * FB ? 16 : (cap <= 20 * FB ? 20 : 24);
+        const int capF = npt * FB;
+        // peak-list capacity: local maxima of the score curve run at ~N/5.6; N/4.4 leaves headroom and
+        // keeps three workgroups per CU resident (a read with more peaks takes the slow path)
+        const int capP = npt == 16 ? 1152 : (npt == 20 ? 1280 : 1408);
+        const size_t flds = fast_lds_bytes(capF, capP);
+        unsigned *count = reinterpret_cast<unsigned *>(d_ws);
+        int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
+        WDX_HIP_TRY(hipMemsetAsync(count, 0, 16, stream));
+        FastArgs F{A, capF, capP, count, list};
+        void (*kern)(FastArgs) = nullptr;
+        if (d_prof) kern = npt == 16 ? fingerprint_fast_kernel<16, true>
+                         : npt == 20 ? fingerprint_fast_kernel<20, true>
+                                     : fingerprint_fast_kernel<24, true>;
+        else kern = npt == 16 ? fingerprint_fast_kernel<16, false>
+                  : npt == 20 ? fingerprint_fast_kernel<20, false>
+                              : fingerprint_fast_kernel<24, false>;
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)flds));
+        const int64_t slice = 1 << 23;  // x 256 threads < 2^32
+        for (int64_t base = 0; base < n_reads; base += slice) {
+            const int64_t n = n_reads - base < slice ? n_reads - base : slice;
+            F.a.block_base = base;
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(FB), flds, stream, F);
+            if (n_launches) ++*n_launches;
+        }
+        WDX_HIP_TRY(hipGetLastError());
+        return small ? launch_fp_list<512>(A, lds, count, list, stream)
+                     : launch_fp_list<1024>(A, lds, count, list, stream);
+    }
+    return small ? launch_fp_chunks<512, false>(A, lds, stream, n_launches)
+                 : launch_fp_chunks<1024, false>(A, lds, stream, n_launches);
 }
 
 }  // namespace wdx
