@@ -52,28 +52,31 @@ def _cpu_minibatch(args):
 
 
 def cpu_baseline(sig_h, off_h, a_s_h, a_e_h, refs, gpu_call, gpu_status, gpu_dist):
-    """Oracle (kind="port") on all host cores over 1000-read minibatches + a 1-core figure; also
-    returns whether the GPU results on the same sample are identical."""
+    """Oracle (kind="port") on all host cores, minibatches farmed to a process pool like
+    file_proc.run_demux, + a 1-core figure; also returns whether the GPU results on the same sample
+    are identical."""
     from concurrent.futures import ProcessPoolExecutor
 
     n = off_h.size - 1
     cores = os.cpu_count() or 1
+    mb = max(100, min(1000, -(-n // cores)))  # reference minibatch is 1000 reads; shrink to occupy every core
     jobs = []
-    for lo in range(0, n, 1000):
-        hi = min(n, lo + 1000)
+    for lo in range(0, n, mb):
+        hi = min(n, lo + mb)
         o = off_h[lo:hi + 1]
         jobs.append((sig_h[o[0]:o[-1]], (o - o[0]).copy(), a_s_h[lo:hi], a_e_h[lo:hi], refs))
-    # 1 core: the first two minibatches
+    # 1 core: a few minibatches in this process
+    n1 = max(1, min(len(jobs), 2000 // mb))
     t0 = time.perf_counter()
-    one = [_cpu_minibatch(j) for j in jobs[:2]]
+    one = [_cpu_minibatch(j) for j in jobs[:n1]]
     t1 = time.perf_counter()
-    n_one = sum(j[2].size for j in jobs[:2])
-    single = n_one / (t1 - t0)
-    # all cores
-    t0 = time.perf_counter()
+    single = sum(j[2].size for j in jobs[:n1]) / (t1 - t0)
+    del one
     with ProcessPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(_cpu_noop, range(cores * 2)))  # start the workers before the clock
+        t0 = time.perf_counter()
         res = list(ex.map(_cpu_minibatch, jobs))
-    t1 = time.perf_counter()
+        t1 = time.perf_counter()
     multi = n / (t1 - t0)
     call = np.concatenate([r[0] for r in res])
     status = np.concatenate([r[1] for r in res])
@@ -81,8 +84,11 @@ def cpu_baseline(sig_h, off_h, a_s_h, a_e_h, refs, gpu_call, gpu_status, gpu_dis
     ok = status == 0
     parity = bool(np.array_equal(call, gpu_call) and np.array_equal(status, gpu_status)
                   and np.array_equal(D, gpu_dist[ok]))
-    del one
-    return multi, cores, single, parity
+    return multi, cores, single, parity, mb
+
+
+def _cpu_noop(i):
+    return i
 
 
 def make_refs(spec_clean, synth, sig_proc):
@@ -112,8 +118,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C3 = 10 M)")
-    ap.add_argument("--cpu-sample", type=int, default=16000, help="reads timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=64000, help="reads timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--calib", action="store_true", help="also stream the signal buffer once with the calibration "
+                    "kernel (known byte count for the FETCH_SIZE counter; tools/collect_traffic.py)")
     args = ap.parse_args()
 
     import torch
@@ -160,6 +168,13 @@ def main():
         eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, out=res)
         dist.reduce_counts(res.counts)
 
+    if args.calib:
+        import ctypes as C
+
+        dummy = torch.zeros(4, dtype=torch.float32, device=tdev)
+        _lib.check(eng.L.wdx_calib_read_dev(eng.ctx.handle, C.c_void_p(sig.data_ptr()), total_samples,
+                                            C.c_void_p(dummy.data_ptr()), None))
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     eng.kernel_time_reset()
@@ -192,11 +207,22 @@ def main():
     fp_bytes = 4.0 * total_samples + 8.0 * K_FPT * n_ok + 4.0 * n_reads
     dtw_bytes = (8.0 * K_FPT + 4.0 * N_BARCODES + 4.0) * n_reads
     if fp_ms >= dtw_ms:
-        dom, dom_ms, dom_n, dom_bytes = "fingerprint_kernel", fp_ms, fp_n, fp_bytes
+        dom, dom_ms, dom_n, dom_bytes = "fingerprint_fast_kernel", fp_ms, fp_n, fp_bytes
     else:
         dom, dom_ms, dom_n, dom_bytes = "dtw_band_kernel<15>", dtw_ms, dtw_n, dtw_bytes
     avg_ms = dom_ms / max(dom_n, 1)
+    dom_bytes = dom_bytes / max(dom_n // max(args.steps, 1), 1)  # per kernel launch (a step may be sliced)
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic of that kernel from the PMC passes (profiles/traffic.json, written by
+    # tools/collect_traffic.py on the same workload); null when not collected for this size
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            tj = json.load(fh)
+        if tj.get("kernel") == dom and tj.get("reads_per_launch") == n_reads // max(dom_n // max(args.steps, 1), 1):
+            traffic = tj.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
 
     out = None
     if rank == 0:
@@ -232,7 +258,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": dom_n,
@@ -254,7 +280,7 @@ def main():
         end = int(off[ns].item())
         sig_h = sig[:end].cpu().numpy()
         off_h = off[: ns + 1].cpu().numpy()
-        multi, cores, single, parity = cpu_baseline(
+        multi, cores, single, parity, mb = cpu_baseline(
             sig_h, off_h, a_s[:ns].cpu().numpy(), a_e[:ns].cpu().numpy(), refs,
             res.call[:ns].cpu().numpy(), res.status[:ns].cpu().numpy(), res.dist[:ns].cpu().numpy())
         out["cpu_baseline"] = {
@@ -262,8 +288,9 @@ def main():
             "unit": "reads/s",
             "cores": cores,
             "kind": "port",
-            "sample": "first %d reads of the same workload, oracle/wdx_oracle.c driven as 1000-read minibatches over "
-                      "a ProcessPoolExecutor(%d) like file_proc.run_demux; dtaidistance itself is not available" % (ns, cores),
+            "sample": "first %d reads of the same workload, oracle/wdx_oracle.c driven as %d-read minibatches over "
+                      "a ProcessPoolExecutor(%d) like file_proc.run_demux (IPC included); dtaidistance itself is "
+                      "not available" % (ns, mb, cores),
             "single_core_value": single,
         }
         out["parity_on_sample"] = parity

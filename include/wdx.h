@@ -171,6 +171,10 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
                                 int64_t prof_reads, int32_t fast_path, void *stream);
 
+/* Diagnostic: stream n floats with coalesced dword loads (known byte count) to calibrate the
+ * FETCH_SIZE PMC counter for the fingerprint kernel's access pattern. */
+int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream);
+
 /* ---- synthetic input generator (bench / tests; spec "wdx-synth v1", warpdemux_amd/synth.py) */
 
 /* Lengths (incl. both 100-sample pads) of reads first_read .. first_read+n-1 -> d_len int64[n] */

@@ -1,0 +1,99 @@
+"""Multi-process path on CPU (gloo, world_size 2): sharding + call-count all-reduce.
+
+The GPU bench uses the same functions with the nccl (= RCCL) backend; here the per-rank "calls" are
+produced by the CPU oracle so that no GPU is needed -- what is under test is warpdemux_amd.dist.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import dist, synth
+
+    r, lr, w = dist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    lo, hi = dist.shard_range(n_total, rank, world)
+    spec = synth.SynthSpec(n_barcodes=4)
+    K = 25
+    refs = np.random.default_rng(0).normal(size=(4, K))
+    sig, off, a_s, a_e, bc = synth.generate_packed(spec, lo, hi - lo)
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig, off, a_s, a_e, orc.SegParams(barcode_num_events=K))
+    ok = status == 0
+    call = np.full(hi - lo, 4, dtype=np.int64)
+    call[ok] = orc.argmin_rows(orc.dtw_matrix(fpt[ok], refs, 15, 0.1))
+    counts = torch.from_numpy(np.bincount(call, minlength=5).astype(np.int64))
+    local = counts.clone()
+    dist.barrier()
+    dist.reduce_counts(counts)
+    t = dist.max_over_ranks(float(rank + 1))
+    out_q.put((rank, lo, hi, local.numpy(), counts.numpy(), t))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_count_allreduce():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_total = 37   # odd on purpose: ragged shards
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, l0, g0, t0), (r1, lo1, hi1, l1, g1, t1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37)
+    assert np.array_equal(g0, g1) and np.array_equal(g0, l0 + l1)
+    assert g0.sum() == n_total
+    assert t0 == t1 == 2.0
+
+    # the same reads in ONE process give the same histogram: sharding is by global read index
+    sys.path.insert(0, ROOT)
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import synth
+
+    spec = synth.SynthSpec(n_barcodes=4)
+    refs = np.random.default_rng(0).normal(size=(4, 25))
+    sig, off, a_s, a_e, bc = synth.generate_packed(spec, 0, n_total)
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig, off, a_s, a_e, orc.SegParams(barcode_num_events=25))
+    ok = status == 0
+    call = np.full(n_total, 4, dtype=np.int64)
+    call[ok] = orc.argmin_rows(orc.dtw_matrix(fpt[ok], refs, 15, 0.1))
+    assert np.array_equal(np.bincount(call, minlength=5), g0)
+
+
+def test_single_process_helpers_are_noops():
+    import torch
+
+    from warpdemux_amd import dist
+
+    c = torch.arange(5, dtype=torch.int64)
+    assert torch.equal(dist.reduce_counts(c.clone()), c)
+    assert dist.max_over_ranks(3.5) == 3.5
+    dist.barrier()
+    assert dist.env_rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+                                     int(os.environ.get("WORLD_SIZE", 1)))

@@ -584,6 +584,12 @@ int wdx_kernel_time_reset(wdx_ctx *ctx) {
     return WDX_SUCCESS;
 }
 
+int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return launch_calib_read(d_p, n, d_out, (hipStream_t)stream);
+}
+
 int wdx_synth_lengths_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
                           int32_t n_barcodes, const int32_t *d_dwell_table, int64_t *d_len,
                           void *stream) {

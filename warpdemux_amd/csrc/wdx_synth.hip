@@ -89,6 +89,22 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(
     }
 }
 
+// Diagnostic: streams n floats with one coalesced dword load per lane (the fingerprint kernel's
+// global access pattern) so the FETCH_SIZE counter can be calibrated against a known byte count.
+__global__ void calib_read_dword_kernel(const float *__restrict__ p, int64_t n, float *__restrict__ out) {
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        acc += p[i];
+    if (acc == 123456.789f) out[0] = acc;  // keep the loads alive without a measurable write
+}
+
+int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(calib_read_dword_kernel, dim3(256 * 8), dim3(256), 0, stream, p, n, out);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_synth_lengths(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,
                          const int32_t *dwell_table, int64_t *d_len, hipStream_t stream) {
     (void)n_barcodes;
