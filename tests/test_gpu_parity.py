@@ -276,6 +276,28 @@ def test_fingerprint_long_rows_and_capacity():
             assert _same(fb.fpt[i], fpt[i]) and _same(fb.dwell[i], dwell[i]) and _same(fb.stats[i], stats[i])
 
 
+def test_fingerprint_empty_and_ragged_inputs():
+    """zero reads, zero-width rows, rows shorter than the adapter window, ragged packed batch"""
+    p = sig_proc.SegParams()
+    fb = sig_proc.fingerprint_batch(np.zeros((0, 100), np.float32), [], [], p)
+    assert fb.fpt.shape == (0, 25) and fb.status.shape == (0,)
+    fb = sig_proc.fingerprint_batch(np.zeros((3, 0), np.float32), [0, 0, 0], [0, 0, 0], p)
+    assert fb.status.tolist() == [5, 5, 5]            # empty window -> "unknown" like the reference (tiny_0)
+    spec = synth.SynthSpec(n_barcodes=4)
+    sig, off, a_s, a_e, _ = synth.generate_packed(spec, 900, 40)
+    # ragged minibatch: every row truncated at a different length (NaN tail), some inside the adapter
+    stride = 5200
+    mb = np.full((40, stride), np.nan, dtype=np.float32)
+    for i in range(40):
+        row = sig[off[i]:off[i + 1]][: stride - 37 * i]
+        mb[i, : row.size] = row
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, p)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams())
+    assert np.array_equal(fb.status, status) and len(set(status.tolist())) >= 2
+    good = status == 0
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good])
+
+
 def test_detect_results_to_fpt_shim():
     from types import SimpleNamespace as NS
 
