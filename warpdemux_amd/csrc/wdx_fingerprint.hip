@@ -829,28 +829,24 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                          p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
                          !getenv("WDX_FORCE_SLOW");
     if (fast_ok) {
-        // samples per thread: the smallest instantiation that holds the longest adapter window,
-        // capped at 24 (longer reads take the slow path)
-        const int npt = cap <= 16 * FB ? 16 : (cap <= 20 * FB ? 20 : 24);
-        const int capF = npt * FB;
+        // samples per thread: the smaller instantiation when the longest adapter window allows it;
+        // windows beyond 6144 samples take the slow path
+        const bool small_fast = cap <= 4096;
+        const int capF = small_fast ? 4096 : 6144;
         // peak-list capacity: local maxima of the score curve run at ~N/5.6; N/4.4 leaves headroom and
         // keeps three workgroups per CU resident (a read with more peaks takes the slow path)
-        const int capP = npt == 16 ? 1152 : (npt == 20 ? 1280 : 1408);
+        const int capP = small_fast ? 1152 : 1408;
         const size_t flds = fast_lds_bytes(capF, capP);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
         WDX_HIP_TRY(hipMemsetAsync(count, 0, 16, stream));
         FastArgs F{A, capF, capP, count, list};
         void (*kern)(FastArgs) = nullptr;
-        if (d_prof) kern = npt == 16 ? fingerprint_fast_kernel<16, true>
-                         : npt == 20 ? fingerprint_fast_kernel<20, true>
-                                     : fingerprint_fast_kernel<24, true>;
-        else kern = npt == 16 ? fingerprint_fast_kernel<16, false>
-                  : npt == 20 ? fingerprint_fast_kernel<20, false>
-                              : fingerprint_fast_kernel<24, false>;
+        if (d_prof) kern = small_fast ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptLarge, true>;
+        else kern = small_fast ? fingerprint_fast_kernel<kNptSmall, false> : fingerprint_fast_kernel<kNptLarge, false>;
         WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)flds));
-        const int64_t slice = 1 << 23;  // x 256 threads < 2^32
+        const int64_t slice = (1ll << 31) / FB;  // grid.x * block.x must stay below 2^32
         for (int64_t base = 0; base < n_reads; base += slice) {
             const int64_t n = n_reads - base < slice ? n_reads - base : slice;
             F.a.block_base = base;
