@@ -129,12 +129,19 @@ def main():
     from warpdemux_amd import _lib, dist, sig_proc, synth
     from warpdemux_amd.engine import DemuxEngine
 
-    rank, local_rank, world = dist.init_process_group()
+    # one process per GPU; backend "nccl" (= RCCL over xGMI).  WDX_BENCH_BACKEND=gloo lets the
+    # multi-process logic be exercised on a box with fewer GPUs than ranks (ranks then share devices).
+    backend = os.environ.get("WDX_BENCH_BACKEND") or None
+    n_dev = torch.cuda.device_count()
+    if backend == "gloo" and n_dev > 0:
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
+    rank, local_rank, world = dist.init_process_group(backend)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     tdev = torch.device("cuda", local_rank)
+    host_collectives = backend == "gloo"
 
     spec = synth.SynthSpec(n_barcodes=N_BARCODES)
     clean = synth.SynthSpec(n_barcodes=N_BARCODES, noise_sigma=0.25, spikes=False)
@@ -166,7 +173,12 @@ def main():
     def step():
         res.counts.zero_()
         eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, out=res)
-        dist.reduce_counts(res.counts)
+        if host_collectives:
+            c = res.counts.cpu()
+            dist.reduce_counts(c)
+            res.counts.copy_(c)
+        else:
+            dist.reduce_counts(res.counts)
 
     if args.calib:
         import ctypes as C
@@ -188,7 +200,7 @@ def main():
     dist.barrier()
     t1 = time.perf_counter()
     eng.kernel_timing(False)
-    elapsed = dist.max_over_ranks(t1 - t0, device=tdev if world > 1 else None)
+    elapsed = dist.max_over_ranks(t1 - t0, device=tdev if (world > 1 and not host_collectives) else None)
 
     fp_ms, fp_n = eng.kernel_time(_lib.K_FINGERPRINT)
     dtw_ms, dtw_n = eng.kernel_time(_lib.K_DTW)

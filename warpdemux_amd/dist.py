@@ -35,6 +35,8 @@ def init_process_group(backend: str | None = None):
     rank, local_rank, world = env_rank_world()
     if world == 1 or dist.is_initialized():
         return rank, local_rank, world
+    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"rank {rank}: LOCAL_RANK {local_rank} has no GPU (visible: {torch.cuda.device_count()})")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
