@@ -106,7 +106,13 @@ def make_refs(spec_clean, synth, sig_proc):
         mb[b, : r.size] = r
     a_s = np.full(N_BARCODES, synth.PAD, dtype=np.int32)
     a_e = np.array([r.size - synth.PAD for r in rows], dtype=np.int32)
-    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=K_FPT))
+    # the 10 template reads go through the exact one-kernel path so that every launch of the fast kernel
+    # seen by a profiler belongs to the timed workload (same results either way)
+    os.environ["WDX_FORCE_SLOW"] = "1"
+    try:
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=K_FPT))
+    finally:
+        del os.environ["WDX_FORCE_SLOW"]
     if not (fb.status == 0).all():
         raise RuntimeError("template fingerprinting failed")
     return fb.fpt
