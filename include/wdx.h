@@ -164,12 +164,13 @@ int wdx_kernel_time_reset(wdx_ctx *ctx);
  * stamps at the phase boundaries P0..P7, 10 = suppression iterations, 11 = adapter samples,
  * 12 = score positions / peaks).  fast_path selects the 256-thread fast kernel (+ slow-path list;
  * slot 15 of read 0 then holds the number of reads it declined) or the one-kernel exact path.
+ * stop_phase k > 0 makes the fast kernel return after phase k (ablation timing; results are garbage).
  * Outputs other than d_status are discarded.  Never on the product path. */
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                                 int64_t stride, int64_t max_len, int64_t n_reads,
                                 const int32_t *d_a_start, const int32_t *d_a_end,
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
-                                int64_t prof_reads, int32_t fast_path, void *stream);
+                                int64_t prof_reads, int32_t fast_path, int32_t stop_phase, void *stream);
 
 /* Diagnostic: largest relative error of the hardware reciprocal-square-root approximation
  * (v_rsq_f64) against 1/sqrt(x) over n log-uniform inputs in [2^-lo_exp, 2^hi_exp).  The fast

@@ -25,7 +25,7 @@ prof = torch.zeros((n, 32), dtype=torch.int64, device="cuda")
 pc = eng.params.to_c()
 for _ in range(2):
     _lib.check(eng.L.wdx_fingerprint_profile_dev(eng.ctx.handle, _dp(sig), _dp(off), 0, max_len, n, _dp(a_s), _dp(a_e),
-                                                 C.byref(pc), _dp(status), _dp(prof), n, fast, None))
+                                                 C.byref(pc), _dp(status), _dp(prof), n, fast, 0, None))
 torch.cuda.synchronize()
 p = prof.cpu().numpy()
 ok = status.cpu().numpy() == 0
@@ -61,3 +61,27 @@ if fast:
         print(f"    {name:12s} {np.median((cur - prev)[okm]):8.0f}   (n={okm.sum()})")
         prev = np.where(okm, cur, prev)
     print("    small-list size median %d p99 %d" % (np.median(q[:, 6]), np.percentile(q[:, 6], 99)))
+
+if fast and len(sys.argv) > 3:
+    # ablation: throughput of the kernel cut after phase k (no stamps: prof_reads = 0), steady state
+    nbig = int(sys.argv[3])
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, nbig)
+    status = torch.empty(nbig, dtype=torch.int32, device="cuda")
+    prof1 = torch.zeros((1, 32), dtype=torch.int64, device="cuda")
+    names = ["P0 load", "P1a median", "P1b MAD+clip", "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E",
+             "P5 boundaries", "P6 event means", "P7 normalise"]
+    prev = 0.0
+    print(f"ablation on {nbig} reads (ms per launch, cumulative / marginal):")
+    for k in list(range(1, 10)):
+        ts = []
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(eng.L.wdx_fingerprint_profile_dev(eng.ctx.handle, _dp(sig), _dp(off), 0, max_len, nbig, _dp(a_s),
+                                                         _dp(a_e), C.byref(pc), _dp(status), _dp(prof1), 0, 1, k, None))
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t = min(ts)
+        print(f"  after {names[k-1]:24s} {t:8.2f}  +{t - prev:7.2f}")
+        prev = t

@@ -133,7 +133,7 @@ def load():
         L.wdx_kernel_time_reset.restype = C.c_int
         L.wdx_kernel_time_reset.argtypes = [vp]
         L.wdx_fingerprint_profile_dev.restype = C.c_int
-        L.wdx_fingerprint_profile_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, P(SegParamsC), vp, vp, i64, i32, vp]
+        L.wdx_fingerprint_profile_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, P(SegParamsC), vp, vp, i64, i32, i32, vp]
         L.wdx_rsq_probe.restype = C.c_int
         L.wdx_rsq_probe.argtypes = [vp, i64, i32, i32, P(f64)]
         L.wdx_calib_read_dev.restype = C.c_int

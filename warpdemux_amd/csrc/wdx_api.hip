@@ -386,7 +386,7 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
                                 int64_t stride, int64_t max_len, int64_t n_reads,
                                 const int32_t *d_a_start, const int32_t *d_a_end,
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
-                                int64_t prof_reads, int32_t fast_path, void *stream) {
+                                int64_t prof_reads, int32_t fast_path, int32_t stop_phase, void *stream) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!p || !d_prof || !d_status) {
@@ -397,8 +397,8 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     rc = launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
                             nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
-                            fast_path ? ctx->fp_ws.p : nullptr, nullptr, d_prof, prof_reads);
-    if (rc == WDX_SUCCESS && fast_path && prof_reads > 0) {
+                            fast_path ? ctx->fp_ws.p : nullptr, nullptr, d_prof, prof_reads, stop_phase);
+    if (rc == WDX_SUCCESS && fast_path && prof_reads > 0 && stop_phase == 0) {
         // slot 15 of read 0 <- number of reads the fast kernel handed to the slow path
         WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         unsigned cnt = 0;

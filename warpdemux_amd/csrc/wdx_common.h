@@ -66,7 +66,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
                        int64_t *n_launches = nullptr, long long *d_prof = nullptr,
-                       int64_t prof_reads = 0);
+                       int64_t prof_reads = 0, int stop_phase = 0);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------

@@ -50,8 +50,9 @@ struct FpArgs {
     int32_t *status;
     int cap;             // LDS capacity in samples
     int64_t block_base;  // first read of this launch (grid.x * block.x must stay below 2^32)
-    long long *prof;     // diagnostic build only: 16 cycle stamps per read
+    long long *prof;     // diagnostic build only: 32 int64 per read (cycle stamps etc.)
     int64_t prof_reads;
+    int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
 };
 
 struct alignas(8) FpShared {
@@ -781,7 +782,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws, int64_t *n_launches, long long *d_prof,
-                       int64_t prof_reads) {
+                       int64_t prof_reads, int stop_phase) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (n_reads > 0x7fffffffLL) {
         set_error("at most 2^31-1 reads per call");
@@ -812,7 +813,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase};
     const size_t lds = fp_lds_bytes(cap);
     if (lds > 160 * 1024) {
         set_error("fingerprint LDS carve-up (%zu B) exceeds 160 KiB", lds);
