@@ -172,11 +172,6 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
                                 int64_t prof_reads, int32_t fast_path, int32_t stop_phase, void *stream);
 
-/* Diagnostic: largest relative error of the hardware reciprocal-square-root approximation
- * (v_rsq_f64) against 1/sqrt(x) over n log-uniform inputs in [2^-lo_exp, 2^hi_exp).  The fast
- * fingerprint kernel classifies local maxima from dm * rsq(vs) with a 2^-18 guard band. */
-int wdx_rsq_probe(wdx_ctx *ctx, int64_t n, int32_t lo_exp, int32_t hi_exp, double *max_rel_err);
-
 /* Diagnostic: stream n floats with coalesced dword loads (known byte count) to calibrate the
  * FETCH_SIZE PMC counter for the fingerprint kernel's access pattern. */
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream);

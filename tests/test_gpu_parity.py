@@ -243,18 +243,6 @@ def test_fast_and_slow_paths_agree(monkeypatch):
             assert _same(fast.stats[good], stats[good])
 
 
-def test_rsq_guard_band_assumption():
-    """The fast kernel decides `a < b` from dm * v_rsq_f64(vs) with a 2^-18 guard band; that is sound
-    while the hardware approximation stays within 2^-21 of 1/sqrt(x)."""
-    import ctypes as C
-
-    ctx = _lib.default_context()
-    err = C.c_double(0)
-    for lo, hi in ((60, 60), (300, 300), (1000, 1000)):
-        _lib.check(_lib.load().wdx_rsq_probe(ctx.handle, 1 << 24, lo, hi, C.byref(err)))
-        assert 0.0 < err.value < 2.0 ** -21, (lo, hi, err.value)
-
-
 def test_fingerprint_long_rows_and_capacity():
     """adapter windows up to the on-chip capacity (1024-thread / one-workgroup-per-CU carve-up)"""
     rng = np.random.default_rng(12)

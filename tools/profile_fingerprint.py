@@ -72,7 +72,7 @@ if fast and len(sys.argv) > 3:
              "P5 boundaries", "P6 event means", "P7 normalise"]
     prev = 0.0
     print(f"ablation on {nbig} reads (ms per launch, cumulative / marginal):")
-    for k in list(range(1, 10)):
+    for k in [1, 21, 22, 23, 24] + list(range(2, 10)):
         ts = []
         for rep in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -83,5 +83,6 @@ if fast and len(sys.argv) > 3:
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         t = min(ts)
-        print(f"  after {names[k-1]:24s} {t:8.2f}  +{t - prev:7.2f}")
+        nm = names[k - 1] if k < 20 else {21: "  med1: hist pass", 22: "  med1: scan+locate", 23: "  med1: gather", 24: "  med1: (rank) = all"}[k]
+        print(f"  after {nm:24s} {t:8.2f}  +{t - prev:7.2f}")
         prev = t

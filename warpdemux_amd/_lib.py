@@ -32,7 +32,7 @@ EXPORTS = [
     "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_dtw_matrix_dev",
     "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
-    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_rsq_probe",
+    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
 ]
 
 
@@ -134,8 +134,6 @@ def load():
         L.wdx_kernel_time_reset.argtypes = [vp]
         L.wdx_fingerprint_profile_dev.restype = C.c_int
         L.wdx_fingerprint_profile_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, P(SegParamsC), vp, vp, i64, i32, i32, vp]
-        L.wdx_rsq_probe.restype = C.c_int
-        L.wdx_rsq_probe.argtypes = [vp, i64, i32, i32, P(f64)]
         L.wdx_calib_read_dev.restype = C.c_int
         L.wdx_calib_read_dev.argtypes = [vp, vp, i64, vp, vp]
         L.wdx_synth_lengths_dev.restype = C.c_int

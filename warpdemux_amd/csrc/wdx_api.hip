@@ -584,21 +584,6 @@ int wdx_kernel_time_reset(wdx_ctx *ctx) {
     return WDX_SUCCESS;
 }
 
-int wdx_rsq_probe(wdx_ctx *ctx, int64_t n, int32_t lo_exp, int32_t hi_exp, double *max_rel_err) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
-    if (!max_rel_err || n <= 0 || lo_exp + hi_exp <= 0) {
-        set_error("rsq_probe: bad arguments");
-        return WDX_ERR_INVALID;
-    }
-    std::lock_guard<std::mutex> g(ctx->mu);
-    if ((rc = ctx->tmp0.ensure(8))) return rc;
-    WDX_HIP_TRY(hipMemset(ctx->tmp0.p, 0, 8));
-    if ((rc = launch_rsq_probe(n, lo_exp, hi_exp, (unsigned long long *)ctx->tmp0.p, nullptr))) return rc;
-    WDX_HIP_TRY(hipMemcpy(max_rel_err, ctx->tmp0.p, 8, hipMemcpyDeviceToHost));
-    return WDX_SUCCESS;
-}
-
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream) {
     int rc = check_ctx(ctx);
     if (rc) return rc;

@@ -77,7 +77,6 @@ int launch_synth_fill(uint64_t seed, int64_t first_read, int64_t n, int32_t n_ba
                       const int32_t *dwell_table, const float *lead, const float *bc,
                       const int64_t *off, float *sig, int32_t *barcode, hipStream_t stream);
 
-int launch_rsq_probe(int64_t n, int lo_exp, int hi_exp, unsigned long long *d_max_bits, hipStream_t stream);
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream);
 
 }  // namespace wdx

@@ -99,30 +99,6 @@ __global__ void calib_read_dword_kernel(const float *__restrict__ p, int64_t n, 
     if (acc == 123456.789f) out[0] = acc;  // keep the loads alive without a measurable write
 }
 
-// Diagnostic: largest relative error of v_rsq_f64 against 1/sqrt(x) over n log-uniform inputs in
-// [2^-lo_exp, 2^hi_exp); the fast fingerprint kernel's guard band (2^-18) relies on it being < 2^-21.
-__global__ void rsq_probe_kernel(int64_t n, int lo_exp, int hi_exp, unsigned long long *max_bits) {
-    double worst = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t h = synth_hash(0x5eedull, (uint64_t)i, 7, 0);
-        const double mant = 1.0 + (double)(h >> 12) * 0x1p-52;                   // [1, 2)
-        const int e = (int)((h & 0xfffull) % (uint64_t)(lo_exp + hi_exp)) - lo_exp;
-        const double x = ldexp(mant, e);
-        const double approx = __builtin_amdgcn_rsq(x);
-        const double exact = 1.0 / sqrt(x);
-        const double rel = fabs(approx - exact) / exact;
-        worst = rel > worst ? rel : worst;
-    }
-    atomicMax(max_bits, (unsigned long long)__double_as_longlong(worst));  // non-negative doubles order as integers
-}
-
-int launch_rsq_probe(int64_t n, int lo_exp, int hi_exp, unsigned long long *d_max_bits, hipStream_t stream) {
-    hipLaunchKernelGGL(rsq_probe_kernel, dim3(1024), dim3(256), 0, stream, n, lo_exp, hi_exp, d_max_bits);
-    WDX_HIP_TRY(hipGetLastError());
-    return WDX_SUCCESS;
-}
-
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream) {
     hipLaunchKernelGGL(calib_read_dword_kernel, dim3(256 * 8), dim3(256), 0, stream, p, n, out);
     WDX_HIP_TRY(hipGetLastError());
