@@ -243,6 +243,27 @@ def test_fast_and_slow_paths_agree(monkeypatch):
             assert _same(fast.stats[good], stats[good])
 
 
+def test_adc_quantised_signals_match_oracle():
+    """Real pA signals are (int16 + offset) * scale: a few hundred distinct values, hence many exact
+    duplicates (radix bins that never shrink), equal scores, plateaus and ties at the top-E cut.  The
+    engine must still agree with the oracle bit for bit (the oracle's stable tie rule)."""
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 31_000, 600, 9000)
+    scale = np.float32(0.1755)
+    q = np.round(mb / scale).astype(np.float32) * scale          # NaN tail stays NaN
+    coarse = np.round(mb / np.float32(2.0)).astype(np.float32) * np.float32(2.0)
+    for data in (q, coarse):
+        for K in (25, 110):
+            fb = sig_proc.fingerprint_batch(data, a_s, a_e, sig_proc.SegParams(barcode_num_events=K))
+            fpt, dwell, stats, status = orc.fingerprint_batch(data, a_s, a_e, orc.SegParams(barcode_num_events=K))
+            assert np.array_equal(fb.status, status)
+            good = status == 0
+            assert good.sum() > 0
+            assert _same(fb.dwell[good], dwell[good])
+            assert _same(fb.fpt[good], fpt[good])
+            assert _same(fb.stats[good], stats[good])
+
+
 def test_fingerprint_long_rows_and_capacity():
     """adapter windows up to the on-chip capacity (1024-thread / one-workgroup-per-CU carve-up)"""
     rng = np.random.default_rng(12)
