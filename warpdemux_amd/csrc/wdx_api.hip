@@ -20,9 +20,17 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// content hash of the reference set (cache key): 64-bit words, multiply-xorshift mixing
 static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
     const unsigned char *p = (const unsigned char *)data;
-    for (size_t i = 0; i < n; ++i) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) {
         h ^= p[i];
         h *= 0x100000001b3ull;
     }
@@ -188,6 +196,18 @@ int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int
     const int64_t L = R.L;
     const int64_t sb = dtw_scratch_bytes(L, R.window);
     if (sb && (rc = ctx->scratch.ensure((size_t)sb))) return rc;
+    // small problems: one launch of the anti-diagonal wavefront kernel straight from the row-major
+    // inputs (no transpose), then the argmin
+    if (dtw_wavefront_eligible(nX, R.nY, L, R.window)) {
+        {
+            Timed t(ctx, WDX_K_DTW, stream);
+            if ((rc = launch_dtw_wavefront(dX, nX, R.pad, R.Lpad, R.halo, R.nY, L, R.window, R.penalty,
+                                           d_out, stream)))
+                return rc;
+        }
+        if (d_argmin) return launch_argmin(d_out, nX, R.nY, d_argmin, stream);
+        return WDX_SUCCESS;
+    }
     // lanes = reads unless there are too few of them to fill a wave and there are more refs
     const bool lanes_are_reads = nX >= 64 || nX >= R.nY;
     if (lanes_are_reads) {

@@ -44,6 +44,11 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan /
                int64_t L, int window, double penalty, float *out, int64_t sA, int64_t sB,
                int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream);
 int64_t dtw_scratch_bytes(int64_t L, int window);
+// anti-diagonal wavefront kernel for small problems (latency path)
+bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window);
+int launch_dtw_wavefront(const double *X, int64_t nX, const double *Ypad, int64_t Lpad, int halo,
+                         int64_t nY, int64_t L, int window, double penalty, float *out,
+                         hipStream_t stream);
 
 // (n, L) row-major -> (L, ld) read-minor, plus per-series NaN flag (nullable)
 int launch_transpose(const double *src, int64_t n, int64_t L, double *dstT, int64_t ld,

@@ -16,6 +16,7 @@
 #include "wdx_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace wdx {
 
@@ -181,9 +182,111 @@ __global__ __launch_bounds__(64) void dtw_scratch_kernel(
     }
 }
 
+// ---- anti-diagonal wavefront kernel (latency path: few pairs, e.g. the live 100 ms ticks) ----------
+// One 16-lane DPP row per (read, reference) pair, four pairs per wave.  Front k = i + j is evaluated
+// by all lanes at once: lane l holds band offset o = j - i = 2l - 14 on even fronts and 2l - 15 on odd
+// ones, so  up   (i-1, j) = previous front, lane l+1 (even k) / lane l   (odd k)
+//           left (i, j-1) = previous front, lane l   (even k) / lane l-1 (odd k)
+//           diag (i-1,j-1) = front k-2, same lane
+// i.e. one row_shl:1 or row_shr:1 DPP move per front and no LDS traffic for the band; the two series
+// of a pair are staged in LDS once.  2L-1 dependent fronts instead of L*(2w-1) dependent cells: ~15x
+// shorter critical path than the lane-per-pair kernel, at ~1.6x its instruction count per pair, hence
+// only used when the whole problem fits the machine at once.  Same float64 operations per cell.
+constexpr int kWfPairsPerBlock = 16;  // 256 threads
+
+__device__ __forceinline__ double dpp_row_shift(double v, double fill, bool left) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    const int flo = __double2loint(fill), fhi = __double2hiint(fill);
+    if (left) {  // lane l <- lane l+1
+        lo = __builtin_amdgcn_update_dpp(flo, lo, 0x101, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x101, 0xf, 0xf, false);
+    } else {     // lane l <- lane l-1
+        lo = __builtin_amdgcn_update_dpp(flo, lo, 0x111, 0xf, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(fhi, hi, 0x111, 0xf, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void dtw_wavefront_kernel(
+    const double *__restrict__ X, int64_t nX, const double *__restrict__ Ypad, int64_t Lpad, int halo,
+    int nY, int L, int w, double p2, float *__restrict__ out) {
+    extern __shared__ double wf_lds[];  // per pair: x[L], y[L]
+    __shared__ int nanflag[kWfPairsPerBlock];
+    const int tid = threadIdx.x;
+    const int row = tid >> 4, l = tid & 15;
+    const int64_t npairs = nX * (int64_t)nY;
+    const int64_t q = (int64_t)blockIdx.x * kWfPairsPerBlock + row;
+    const bool active = q < npairs;
+    const int64_t qq = active ? q : npairs - 1;
+    const int64_t r = qq / nY;
+    const int c = (int)(qq % nY);
+    double *xs = wf_lds + (size_t)row * 2 * L, *ys = xs + L;
+    if (l == 0) nanflag[row] = 0;
+    __syncthreads();
+    {
+        const double *xg = X + r * L, *yg = Ypad + (int64_t)c * Lpad + halo;
+        int bad = 0;
+        for (int t = l; t < L; t += 16) {
+            const double xv = xg[t], yv = yg[t];
+            bad |= (xv != xv) | (yv != yv);
+            xs[t] = xv;
+            ys[t] = yv;
+        }
+        if (bad) atomicOr(&nanflag[row], 1);
+    }
+    __syncthreads();
+    double prev2 = (l == 7) ? 0.0 : WDX_INF;  // front k-2 (holds the virtual D[0][0] = 0 for cell (0,0))
+    double prev1 = WDX_INF;                     // front k-1
+    double cur = WDX_INF;
+    const int nfront = 2 * L - 1;
+    for (int k = 0; k < nfront; ++k) {
+        const bool odd = k & 1;
+        const int o = 2 * l - (odd ? 15 : 14);
+        const int i = (k - o) >> 1, j = (k + o) >> 1;  // k - o is even by construction
+        const bool valid = (odd || l < 15) && i >= 0 && j >= 0 && i < L && j < L && o <= w - 1 && -o <= w - 1;
+        const double up = odd ? prev1 : dpp_row_shift(prev1, WDX_INF, true);
+        const double left = odd ? dpp_row_shift(prev1, WDX_INF, false) : prev1;
+        const double xv = xs[min(max(i, 0), L - 1)], yv = ys[min(max(j, 0), L - 1)];
+        double d = xv - yv;
+        d = d * d;
+        double t = min_f64(up, left) + p2;
+        t = min_f64(t, prev2);
+        const double v = valid ? d + t : WDX_INF;
+        prev2 = prev1;
+        prev1 = v;
+        cur = v;
+    }
+    // cell (L-1, L-1): last front (even), o = 0 -> lane 7
+    if (active && l == 7) {
+        double res = sqrt(cur);
+        if (nanflag[row]) res = __builtin_nan("");
+        out[q] = (float)res;
+    }
+}
+
 int64_t dtw_scratch_bytes(int64_t L, int window) {
     if (window <= kMaxRegWindow) return 0;
     return 2 * (L + 1) * 65536 * (int64_t)sizeof(double);
+}
+
+// Row-major X (nX, L) against padded refs; out (nX, nY) row-major.  Caller checked eligibility.
+int launch_dtw_wavefront(const double *X, int64_t nX, const double *Ypad, int64_t Lpad, int halo,
+                         int64_t nY, int64_t L, int window, double penalty, float *out,
+                         hipStream_t stream) {
+    const int w = (window <= 0 || window > L) ? (int)L : window;
+    const int64_t npairs = nX * nY;
+    if (npairs == 0) return WDX_SUCCESS;
+    const size_t lds = (size_t)kWfPairsPerBlock * 2 * (size_t)L * sizeof(double);
+    hipLaunchKernelGGL(dtw_wavefront_kernel, dim3((unsigned)((npairs + kWfPairsPerBlock - 1) / kWfPairsPerBlock)),
+                       dim3(256), lds, stream, X, nX, Ypad, Lpad, halo, (int)nY, (int)L, w,
+                       penalty * penalty, out);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window) {
+    const int64_t w = (window <= 0 || window > L) ? L : window;
+    return w <= 16 && L >= 1 && L <= 256 && nX * nY <= 16384 && !getenv("WDX_NO_WAVEFRONT");
 }
 
 int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, const double *Bpad,
