@@ -147,6 +147,15 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                   int32_t *d_status, float *d_dist, int32_t *d_call, int64_t *d_counts,
                   void *d_work, void *stream);
 
+/* Host-buffer form of the fused path (one call per minibatch or per live tick, one synchronisation):
+ * fingerprint the (n_reads, stride) float32 minibatch, DTW every successful read against the resident
+ * reference set (wdx_set_refs; K = p->barcode_num_events must equal its length), nearest-reference call.
+ * Host outputs: status int32[n_reads]; call int32[n_reads] (argmin column, -1 for failed reads);
+ * dist (n_reads, nY) float32 (nullable; NaN rows for failed reads); fpt (n_reads, K) float64 (nullable). */
+int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                    const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                    const wdx_seg_params *p, double *fpt, float *dist, int32_t *call, int32_t *status);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Kernel ids for wdx_kernel_time */

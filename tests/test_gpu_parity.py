@@ -307,6 +307,30 @@ def test_fingerprint_empty_and_ragged_inputs():
     assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good])
 
 
+def test_fused_host_call_matches_separate_calls():
+    spec = synth.SynthSpec(n_barcodes=6)
+    rng = np.random.default_rng(4)
+    for n, K, nY in ((1, 110, 6), (7, 25, 1368), (300, 110, 6)):
+        mb, a_s, a_e, _ = synth.generate_minibatch(spec, 60_000, n, 8000)
+        ok = np.ones(n, dtype=np.uint8)
+        if n > 3:
+            ok[2] = 0
+            a_e[3] = a_s[3] - 100
+        Y = rng.normal(size=(nY, K))
+        p = sig_proc.SegParams(barcode_num_events=K)
+        sig_proc.set_references(Y, 15, 0.1)
+        res = sig_proc.demux_batch(mb, a_s, a_e, p, success=ok, want_fpt=True, n_refs=nY)
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, p, success=ok)
+        assert np.array_equal(res.status, fb.status) and _same(res.fpt, fb.fpt)
+        good = fb.status == 0
+        D, am = pdist.nearest_reference(fb.fpt[good], Y, 15, 0.1)
+        assert _same(res.dist[good], D) and np.isnan(res.dist[~good]).all()
+        assert np.array_equal(res.call[good], am) and (res.call[~good] == -1).all()
+        assert _same(D, orc.dtw_matrix(fb.fpt[good], Y, 15, 0.1))
+    with pytest.raises(ValueError):
+        sig_proc.demux_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=24), n_refs=nY)
+
+
 def test_detect_results_to_fpt_shim():
     from types import SimpleNamespace as NS
 

@@ -81,4 +81,21 @@ for K, nY in ((110, 6), (25, 1368)):
         lat = np.array(lat) * 1e3
         out[f"live_K{K}_nY{nY}_n{n}"] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                                           "reads_per_s": n / float(np.median(lat)) * 1e3}
+# ---- the same ticks through the fused host call (one synchronisation) ---------------------------------
+for K, nY in ((110, 6), (25, 1368)):
+    p = sig_proc.SegParams(barcode_num_events=K)
+    Y = rng.normal(size=(nY, K))
+    sig_proc.set_references(Y, 15, 0.1)
+    for n in (1, 8, 64, 512):
+        sub, s_, e_ = mb[:n], a_s[:n], a_e[:n]
+        lat = []
+        for _ in range(3):
+            sig_proc.demux_batch(sub, s_, e_, p, n_refs=nY)
+        for _ in range(30):
+            t0 = time.perf_counter()
+            sig_proc.demux_batch(sub, s_, e_, p, n_refs=nY)
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat) * 1e3
+        out[f"live_fused_K{K}_nY{nY}_n{n}"] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                                                "reads_per_s": n / float(np.median(lat)) * 1e3}
 print(json.dumps(out, indent=1))

@@ -30,7 +30,7 @@ NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
     "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
+    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
 ]
@@ -120,6 +120,8 @@ def load():
         L.wdx_dtw_matrix_dev.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_fingerprint_batch.restype = C.c_int
         L.wdx_fingerprint_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
+        L.wdx_demux_batch.restype = C.c_int
+        L.wdx_demux_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
         L.wdx_fingerprint_dev.restype = C.c_int
         L.wdx_fingerprint_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp]
         L.wdx_demux_workspace_bytes.restype = i64

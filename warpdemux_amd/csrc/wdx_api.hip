@@ -555,6 +555,77 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
     return launch_count_calls(d_call, d_status, n_reads, R.nY, d_counts, s);
 }
 
+int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                    const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                    const wdx_seg_params *p, double *fpt, float *dist, int32_t *call, int32_t *status) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (n_reads < 0 || stride < 0 || !p || (n_reads > 0 && (!sig || !a_start || !a_end || !call || !status))) {
+        set_error("demux_batch: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    DtwRefs &R = ctx->refs;
+    if (R.window == 0) {
+        set_error("no reference set: call wdx_set_refs first");
+        return WDX_ERR_NO_REFS;
+    }
+    const int64_t K = p->barcode_num_events;
+    if (K != R.L) {
+        set_error("barcode_num_events (%lld) != reference length (%lld)", (long long)K, (long long)R.L);
+        return WDX_ERR_INVALID;
+    }
+    hipStream_t s = nullptr;
+    int64_t max_len = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        if (ok && !ok[r]) continue;
+        int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
+        if (st < 0) st = 0;
+        if (en > stride) en = stride;
+        if (en - st > max_len) max_len = en - st;
+    }
+    const size_t sb = (size_t)(n_reads * stride) * sizeof(float);
+    const size_t db = (size_t)(n_reads * (R.nY > 0 ? R.nY : 1)) * sizeof(float);
+    if ((rc = ctx->in0.ensure(sb ? sb : 4))) return rc;
+    if ((rc = ctx->in1.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->in2.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->in3.ensure((size_t)n_reads))) return rc;
+    if ((rc = ctx->out0.ensure((size_t)(n_reads * K) * 8))) return rc;
+    if ((rc = ctx->out1.ensure(db))) return rc;
+    if ((rc = ctx->out2.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
+    if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, sig, sb, hipMemcpyHostToDevice, s));
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    if (ok) WDX_HIP_TRY(hipMemcpyAsync(ctx->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
+    {
+        Timed t(ctx, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint((const float *)ctx->in0.p, nullptr, nullptr, stride, max_len, n_reads,
+                                     (const int32_t *)ctx->in1.p, (const int32_t *)ctx->in2.p,
+                                     ok ? (const uint8_t *)ctx->in3.p : nullptr, *p, (double *)ctx->out0.p,
+                                     nullptr, nullptr, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p, &t.n_launches)))
+            return rc;
+    }
+    if (R.nY > 0) {
+        if ((rc = dtw_dev_locked(ctx, (const double *)ctx->out0.p, n_reads, (float *)ctx->out1.p,
+                                 (int32_t *)ctx->out2.p, s)))
+            return rc;
+        if ((rc = launch_count_calls((int32_t *)ctx->out2.p, (const int32_t *)ctx->out3.p, n_reads, R.nY,
+                                     nullptr, s)))
+            return rc;
+        WDX_HIP_TRY(hipMemcpyAsync(call, ctx->out2.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+        if (dist) WDX_HIP_TRY(hipMemcpyAsync(dist, ctx->out1.p, db, hipMemcpyDeviceToHost, s));
+    }
+    WDX_HIP_TRY(hipMemcpyAsync(status, ctx->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+    if (fpt) WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipStreamSynchronize(s));
+    if (R.nY == 0)
+        for (int64_t r = 0; r < n_reads; ++r) call[r] = -1;
+    return WDX_SUCCESS;
+}
+
 int wdx_kernel_timing(wdx_ctx *ctx, int enable) {
     int rc = check_ctx(ctx);
     if (rc) return rc;

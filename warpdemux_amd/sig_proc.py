@@ -172,6 +172,56 @@ def fingerprint_batch(signals, adapter_start, adapter_end, params: SegParams, su
     return FingerprintBatch(fpt, dwell, stats, status)
 
 
+@dataclass
+class DemuxBatch:
+    """Result of the fused host call: fingerprint -> DTW -> nearest reference."""
+
+    status: np.ndarray            # (n,) int32 WDX_READ_*
+    call: np.ndarray              # (n,) int32 argmin reference index, -1 for failed reads
+    dist: Optional[np.ndarray]    # (n, nY) float32, NaN rows for failed reads
+    fpt: Optional[np.ndarray]     # (n, K) float64
+
+
+def set_references(refs, window=None, penalty=None, device=None):
+    """Upload the reference set once (model._X) for `demux_batch`; kept resident in the context."""
+    refs = np.ascontiguousarray(refs, dtype=np.float64)
+    if refs.ndim != 2:
+        raise ValueError("refs must be (nY, L)")
+    ctx = _lib.default_context(device)
+    _lib.check(_lib.load().wdx_set_refs(ctx.handle, _lib.ptr(refs), refs.shape[0], refs.shape[1],
+                                        int(window) if window else 0, float(penalty) if penalty else 0.0))
+    return refs.shape
+
+
+def demux_batch(signals, adapter_start, adapter_end, params: SegParams, success=None, want_dist=True,
+                want_fpt=False, n_refs=None, device=None) -> DemuxBatch:
+    """One call per minibatch / live tick: fingerprints, distances to the resident references
+    (`set_references`) and the nearest-reference call, with a single device synchronisation."""
+    sig = np.asarray(signals)
+    if sig.ndim != 2:
+        raise ValueError("signals must be a 2-D (n_reads, stride) array")
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    n, stride = sig.shape
+    a_s = np.ascontiguousarray(adapter_start, dtype=np.int32)
+    a_e = np.ascontiguousarray(adapter_end, dtype=np.int32)
+    if a_s.shape != (n,) or a_e.shape != (n,):
+        raise ValueError("adapter_start/adapter_end must have one entry per read")
+    ok = None if success is None else np.ascontiguousarray(success, dtype=np.uint8)
+    pc = params.to_c()
+    K = params.barcode_num_events
+    if want_dist and n_refs is None:
+        raise ValueError("n_refs (number of resident references) is needed to size the distance matrix")
+    dist = np.empty((n, n_refs), dtype=np.float32) if want_dist else None
+    fpt = np.empty((n, K), dtype=np.float64) if want_fpt else None
+    call = np.empty(n, dtype=np.int32)
+    status = np.empty(n, dtype=np.int32)
+    ctx = _lib.default_context(device)
+    _lib.check(_lib.load().wdx_demux_batch(
+        ctx.handle, _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e), _lib.ptr(ok), C.byref(pc),
+        _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call), _lib.ptr(status)))
+    return DemuxBatch(status, call, dist, fpt)
+
+
 def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequence, read_ids: Optional[Sequence[str]] = None, device=None) -> List[ReadResult]:
     """Batched `detect_results_to_fpt`: one ReadResult per row, identical fields to the reference's
     per-read call (sig_proc.py:590-605) plus the `barcode_fpt_wrapper` read-id (file_proc.py:216)."""
