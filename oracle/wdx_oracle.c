@@ -536,3 +536,116 @@ void wdx_oracle_argmin_rows(const float *D, int64_t nX, int64_t nY, int32_t *cal
         call[r] = best;
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* N1: classifier tail of DTW_SVM.predict (models/dtw_svm.py:21-22, 90-93; models/utils.py:19-61) */
+/*     = libsvm's svm_predict_probability for a precomputed kernel, as sklearn.svm.SVC calls it.  */
+/*     Restated from the published libsvm algorithm (svm.cpp: svm_predict_values, sigmoid_predict, */
+/*     multiclass_probability); pinned against sklearn itself in tests/test_oracle_svm.py.         */
+/* ------------------------------------------------------------------------------------------ */
+
+static double sigmoid_predict(double dec, double A, double B) {
+    double fApB = dec * A + B;
+    if (fApB >= 0) return exp(-fApB) / (1.0 + exp(-fApB));
+    return 1.0 / (1.0 + exp(fApB));
+}
+
+static void multiclass_probability(int k, const double *r /* k x k */, double *p) {
+    int t, j, iter, max_iter = k > 100 ? k : 100;
+    double *Q = (double *)malloc(sizeof(double) * (size_t)k * (size_t)k);
+    double *Qp = (double *)malloc(sizeof(double) * (size_t)k);
+    double pQp, eps = 0.005 / k;
+    for (t = 0; t < k; t++) {
+        p[t] = 1.0 / k;
+        Q[t * k + t] = 0;
+        for (j = 0; j < t; j++) {
+            Q[t * k + t] += r[j * k + t] * r[j * k + t];
+            Q[t * k + j] = Q[j * k + t];
+        }
+        for (j = t + 1; j < k; j++) {
+            Q[t * k + t] += r[j * k + t] * r[j * k + t];
+            Q[t * k + j] = -r[j * k + t] * r[t * k + j];
+        }
+    }
+    for (iter = 0; iter < max_iter; iter++) {
+        pQp = 0;
+        for (t = 0; t < k; t++) {
+            Qp[t] = 0;
+            for (j = 0; j < k; j++) Qp[t] += Q[t * k + j] * p[j];
+            pQp += p[t] * Qp[t];
+        }
+        double max_error = 0;
+        for (t = 0; t < k; t++) {
+            double error = fabs(Qp[t] - pQp);
+            if (error > max_error) max_error = error;
+        }
+        if (max_error < eps) break;
+        for (t = 0; t < k; t++) {
+            double diff = (-Qp[t] + pQp) / Q[t * k + t];
+            p[t] += diff;
+            pQp = (pQp + diff * (diff * Q[t * k + t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+            for (j = 0; j < k; j++) {
+                Qp[j] = (Qp[j] + diff * Q[t * k + j]) / (1 + diff);
+                p[j] /= (1 + diff);
+            }
+        }
+    }
+    free(Q);
+    free(Qp);
+}
+
+/* Kmat: (n, n_train) float64 precomputed kernel rows; support: training-set index of each support
+ * vector (grouped by class, n_support[c] each); dual_coef: (k-1, nSV); rho: k(k-1)/2 (libsvm sign:
+ * sklearn's intercept_ = -rho); probA/probB: k(k-1)/2.  prob: (n, k) in class order.
+ * dec (nullable): (n, k(k-1)/2) one-vs-one decision values. */
+int wdx_oracle_svm_predict_proba(const double *Kmat, int64_t n, int64_t n_train, int k,
+                                 const int32_t *n_support, const int32_t *support,
+                                 const double *dual_coef, const double *rho, const double *probA,
+                                 const double *probB, double *prob, double *dec_out) {
+    int64_t nSV = 0;
+    int *start = (int *)malloc(sizeof(int) * (size_t)k);
+    for (int c = 0; c < k; c++) {
+        start[c] = (int)nSV;
+        nSV += n_support[c];
+    }
+    const int npairs = k * (k - 1) / 2;
+    double *kv = (double *)malloc(sizeof(double) * (size_t)(nSV > 0 ? nSV : 1));
+    double *dec = (double *)malloc(sizeof(double) * (size_t)(npairs > 0 ? npairs : 1));
+    double *pw = (double *)malloc(sizeof(double) * (size_t)k * (size_t)k);
+    const double min_prob = 1e-7;
+    for (int64_t x = 0; x < n; x++) {
+        const double *row = Kmat + x * n_train;
+        for (int64_t s = 0; s < nSV; s++) kv[s] = row[support[s]];
+        int p = 0;
+        for (int i = 0; i < k; i++)
+            for (int j = i + 1; j < k; j++) {
+                double sum = 0;
+                const int si = start[i], sj = start[j], ci = n_support[i], cj = n_support[j];
+                const double *coef1 = dual_coef + (size_t)(j - 1) * nSV, *coef2 = dual_coef + (size_t)i * nSV;
+                for (int q = 0; q < ci; q++) sum += coef1[si + q] * kv[si + q];
+                for (int q = 0; q < cj; q++) sum += coef2[sj + q] * kv[sj + q];
+                sum -= rho[p];
+                dec[p] = sum;
+                if (dec_out) dec_out[x * npairs + p] = sum;
+                p++;
+            }
+        p = 0;
+        for (int i = 0; i < k; i++)
+            for (int j = i + 1; j < k; j++) {
+                double v = sigmoid_predict(dec[p], probA[p], probB[p]);
+                if (v < min_prob) v = min_prob;
+                if (v > 1 - min_prob) v = 1 - min_prob;
+                pw[i * k + j] = v;
+                pw[j * k + i] = 1 - v;
+                p++;
+            }
+        /* scikit-learn's vendored libsvm has no two-class shortcut: the coupling iteration always runs
+         * (probabilities then differ from the plain sigmoid by up to its stopping tolerance) */
+        multiclass_probability(k, pw, prob + x * k);
+    }
+    free(start);
+    free(kv);
+    free(dec);
+    free(pw);
+    return 0;
+}

@@ -97,6 +97,8 @@ def lib():
         L.wdx_oracle_dtw_matrix.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p]
         L.wdx_oracle_argmin_rows.restype = None
         L.wdx_oracle_argmin_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.wdx_oracle_svm_predict_proba.restype = C.c_int
+        L.wdx_oracle_svm_predict_proba.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -201,3 +203,25 @@ def argmin_rows(D) -> np.ndarray:
     out = np.empty(D.shape[0], dtype=np.int32)
     lib().wdx_oracle_argmin_rows(_p(D), D.shape[0], D.shape[1], _p(out))
     return out
+
+
+def svm_params(svc):
+    """The arrays libsvm's predict_probability needs, from a fitted sklearn SVC(kernel="precomputed",
+    probability=True): (n_support i32[k], support i32[nSV], dual_coef f64[(k-1),nSV], rho f64[npairs],
+    probA, probB)."""
+    k = svc.classes_.size
+    rho = -np.asarray(svc._intercept_, dtype=np.float64)          # libsvm's rho (sklearn stores -rho)
+    return (np.ascontiguousarray(svc._n_support, dtype=np.int32), np.ascontiguousarray(svc.support_, dtype=np.int32),
+            np.ascontiguousarray(svc._dual_coef_, dtype=np.float64), np.ascontiguousarray(rho),
+            np.ascontiguousarray(svc._probA, dtype=np.float64), np.ascontiguousarray(svc._probB, dtype=np.float64), k)
+
+
+def svm_predict_proba(K, n_support, support, dual_coef, rho, probA, probB, want_dec=False):
+    K = np.ascontiguousarray(K, dtype=np.float64)
+    n, n_train = K.shape
+    k = n_support.size
+    prob = np.empty((n, k), dtype=np.float64)
+    dec = np.empty((n, k * (k - 1) // 2), dtype=np.float64) if want_dec else None
+    lib().wdx_oracle_svm_predict_proba(_p(K), n, n_train, k, _p(n_support), _p(support), _p(dual_coef), _p(rho),
+                                       _p(probA), _p(probB), _p(prob), None if dec is None else _p(dec))
+    return (prob, dec) if want_dec else prob

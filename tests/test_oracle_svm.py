@@ -1,0 +1,40 @@
+"""N1: the classifier tail of DTW_SVM.predict.  The oracle restates libsvm's
+svm_predict_probability; here it is pinned against scikit-learn's own SVC (the library the reference
+calls at models/dtw_svm.py:92), which is importable wherever these tests run."""
+import numpy as np
+import pytest
+
+from oracle import wdx_oracle as orc
+
+sklearn = pytest.importorskip("sklearn")
+
+
+def make_model(n_classes, n_train, seed, L=25):
+    from sklearn.svm import SVC
+
+    rng = np.random.default_rng(seed)
+    centers = rng.normal(size=(n_classes, L))
+    y = rng.integers(0, n_classes, n_train)
+    Xtr = centers[y] + 0.9 * rng.normal(size=(n_train, L))
+    D = orc.dtw_matrix(Xtr, Xtr, 15, 0.1)
+    K = np.exp(-1.0 * np.power(D, 1))            # pdist_kernel, models/dtw_svm.py:21-22 (float32)
+    svc = SVC(kernel="precomputed", probability=True, C=1.0, random_state=seed).fit(K, y)
+    return svc, Xtr, centers, rng
+
+
+@pytest.mark.parametrize("n_classes,n_train", [(2, 80), (3, 150), (5, 300), (11, 500)])
+def test_predict_proba_matches_sklearn(n_classes, n_train):
+    svc, Xtr, centers, rng = make_model(n_classes, n_train, seed=n_classes)
+    yq = rng.integers(0, n_classes, 64)
+    Xq = centers[yq] + 0.9 * rng.normal(size=(64, Xtr.shape[1]))
+    Kq = np.exp(-1.0 * np.power(orc.dtw_matrix(Xq, Xtr, 15, 0.1), 1))   # float32, like the reference
+    ref = svc.predict_proba(Kq)
+    n_support, support, dual_coef, rho, probA, probB, k = orc.svm_params(svc)
+    got, dec = orc.svm_predict_proba(Kq, n_support, support, dual_coef, rho, probA, probB, want_dec=True)
+    assert got.shape == ref.shape == (64, n_classes)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    # one-vs-one decision values against sklearn's own
+    svc.decision_function_shape = "ovo"
+    sign = -1.0 if n_classes == 2 else 1.0   # sklearn flips the sign of the binary decision function
+    np.testing.assert_allclose(dec, sign * svc.decision_function(Kq).reshape(64, -1), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(np.argmax(got, axis=1), np.argmax(ref, axis=1))
