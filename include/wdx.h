@@ -156,6 +156,33 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
                     const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
                     const wdx_seg_params *p, double *fpt, float *dist, int32_t *call, int32_t *status);
 
+/* ---- N1: classifier tail of DTW_SVM.predict (models/dtw_svm.py:90-93 + models/utils.py:45-61):
+ *      K = exp(-gamma * d^pwr_dist) -> SVC.predict_proba(K) (libsvm, precomputed kernel) -> argmax,
+ *      label map, top1-top2 margin, per-class thresholds.  Arrays are HOST pointers, copied at set time. */
+typedef struct wdx_svm_model {
+    int32_t n_classes;         /* k = len(svc.classes_) (barcodes + noise class), 2..16              */
+    int32_t n_sv;              /* total support vectors                                              */
+    int32_t n_train;           /* columns of the distance matrix = len(model._X)                     */
+    int32_t pwr_dist;          /* DTW_SVM.pwr_dist                                                   */
+    double gamma;              /* DTW_SVM.gamma                                                      */
+    const int32_t *n_support;  /* [k]    svc._n_support                                              */
+    const int32_t *support;    /* [n_sv] svc.support_ (column index of every support vector)         */
+    const double *dual_coef;   /* [(k-1) x n_sv] svc._dual_coef_ (libsvm sign convention)            */
+    const double *rho;         /* [k(k-1)/2]  = -svc._intercept_                                     */
+    const double *probA;       /* [k(k-1)/2]  svc._probA                                             */
+    const double *probB;       /* [k(k-1)/2]  svc._probB                                             */
+    const int32_t *label_map;  /* [k] class index -> barcode label (model.label_mapper); nullable     */
+    const double *thresholds;  /* [k] model.thresholds; nullable = no thresholding                    */
+} wdx_svm_model;
+int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m);
+/* d_dist: (n, n_train) float32 DEVICE distances (wdx_dtw_matrix_dev output); outputs DEVICE, nullable:
+ * d_prob (n,k) float64 = y_prob, d_pred int32[n] = predicted barcode or -1, d_conf float64[n] = margin. */
+int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
+                        double *d_conf, void *stream);
+/* DTW_SVM.predict on host buffers: X (n, L) float64 fingerprints -> DTW against the resident reference
+ * set (wdx_set_refs with model._X, window, penalty) -> SVM tail.  Outputs host, nullable. */
+int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Kernel ids for wdx_kernel_time */

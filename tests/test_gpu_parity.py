@@ -412,3 +412,91 @@ def test_device_synth_matches_numpy_and_fused_pipeline():
     torch.cuda.synchronize()
     assert np.array_equal(res2.counts.cpu().numpy(), 2 * exp)
     eng.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# N1: DTW_SVM.predict -- DTW -> exp kernel -> libsvm predict_probability -> process_probs
+# ----------------------------------------------------------------------------------------------
+def _svm_case(n_classes, n_train, n_query, seed, thresholds=False):
+    from test_oracle_svm import make_model
+    from warpdemux_amd.models import DTW_SVM
+
+    svc, Xtr, centers, rng = make_model(n_classes, n_train, seed=seed)
+    yq = rng.integers(0, n_classes, n_query)
+    Xq = centers[yq] + 0.9 * rng.normal(size=(n_query, Xtr.shape[1]))
+    label_mapper = {i: 3 * i + 1 for i in range(n_classes)}
+    thr = rng.uniform(0.05, 0.6, n_classes) if thresholds else None
+    n_support, support, dual_coef, rho, probA, probB, k = orc.svm_params(svc)
+    m = DTW_SVM(Xtr, n_support, support, dual_coef, rho, probA, probB, label_mapper, thr, window=15, penalty=0.1,
+                gamma=1.0, pwr_dist=1, block_size=2000)
+    return svc, Xtr, Xq, label_mapper, thr, m
+
+
+def _reference_tail(svc, Xtr, Xq, label_mapper, thr):
+    """models/dtw_svm.py:85-98 with the oracle's DTW and scikit-learn's own predict_proba."""
+    Kq = np.exp(-1.0 * np.power(orc.dtw_matrix(Xq, Xtr, 15, 0.1), 1))
+    prob = svc.predict_proba(Kq)
+    idx = np.argmax(prob, axis=1)
+    pred = np.array([label_mapper[i] for i in idx])
+    srt = np.sort(prob, axis=1)
+    conf = srt[:, -1] - srt[:, -2]
+    if thr is not None:
+        pred[conf < thr[idx]] = -1
+    return pred, prob, conf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_classes,n_train,thresholds", [(2, 80, False), (3, 150, True), (5, 300, True),
+                                                          (11, 500, False), (12, 700, True)])
+def test_dtw_svm_predict_matches_sklearn(n_classes, n_train, thresholds):
+    sklearn = pytest.importorskip("sklearn")
+    svc, Xtr, Xq, label_mapper, thr, m = _svm_case(n_classes, n_train, 333, seed=n_classes, thresholds=thresholds)
+    pred_ref, prob_ref, conf_ref = _reference_tail(svc, Xtr, Xq, label_mapper, thr)
+    pred, prob = m.predict(Xq)
+    assert prob.shape == prob_ref.shape and pred.shape == pred_ref.shape
+    # float32 exp on the device may differ from NumPy's by one ulp in the kernel value: 1e-5 on probabilities
+    np.testing.assert_allclose(prob, prob_ref, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(prob.sum(axis=1), 1.0, atol=1e-12)
+    # labels must agree wherever the reference's own decision is not within the tolerance of a tie / threshold
+    srt = np.sort(prob_ref, axis=1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-4
+    if thr is not None:
+        safe &= np.abs(conf_ref - thr[np.argmax(prob_ref, axis=1)]) > 1e-4
+    assert safe.mean() > 0.95
+    assert np.array_equal(pred[safe], pred_ref[safe])
+    if thr is not None:
+        assert (pred_ref == -1).any() and (pred == -1).any()
+    df = m.predict(Xq, return_df=True)
+    assert list(df.columns[:2]) == ["predicted_barcode", "confidence_score"]
+    assert list(df.columns[2:]) == [f"p{label_mapper[i]:02d}" for i in range(n_classes)]
+    np.testing.assert_allclose(df["confidence_score"].to_numpy(), conf_ref, atol=1.5e-3)
+    assert np.array_equal(df["predicted_barcode"].to_numpy(), pred)
+
+
+@pytest.mark.gpu
+def test_dtw_svm_predict_matches_oracle_on_device_kernel_values():
+    """With the kernel matrix the device itself produced the oracle's libsvm restatement must agree to
+    double rounding: isolates the classifier tail from the float32 exp."""
+    pytest.importorskip("sklearn")
+    svc, Xtr, Xq, label_mapper, thr, m = _svm_case(5, 300, 200, seed=9)
+    D = pdist.distance_matrix_to(Xq, Xtr, window=15, penalty=0.1, n_jobs=1)
+    assert np.array_equal(D, orc.dtw_matrix(Xq, Xtr, 15, 0.1))
+    pred, prob = m.predict(Xq)
+    pr = svc.predict_proba(np.exp(-1.0 * D))
+    np.testing.assert_allclose(prob, pr, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_dtw_svm_predict_errors_and_single_row():
+    pytest.importorskip("sklearn")
+    svc, Xtr, Xq, label_mapper, thr, m = _svm_case(3, 150, 8, seed=4)
+    p1, q1 = m.predict(Xq[0])
+    pa, qa = m.predict(Xq)
+    assert p1.shape == (1,) and q1.shape == (1, 3)
+    assert p1[0] == pa[0] and np.array_equal(q1[0], qa[0])
+    with pytest.raises(ValueError):
+        m.predict(Xq[:, :-1])
+    m.block_size = None
+    with pytest.raises(ValueError):
+        m.predict(Xq)             # nproc=-1 without block_size, like the reference
+    assert m.predict(Xq, nproc=1)[0].shape == (8,)

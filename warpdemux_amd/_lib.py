@@ -30,7 +30,8 @@ NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
     "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_workspace_bytes", "wdx_demux_dev",
+    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_svm_set_model",
+    "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
 ]
@@ -49,6 +50,26 @@ class SegParamsC(C.Structure):
         ("accept_less_cpts", C.c_int32),
         ("seg_norm", C.c_int32),
         ("barcode_num_events", C.c_int32),
+    ]
+
+
+class SvmModelC(C.Structure):
+    """wdx_svm_model (include/wdx.h)"""
+
+    _fields_ = [
+        ("n_classes", C.c_int32),
+        ("n_sv", C.c_int32),
+        ("n_train", C.c_int32),
+        ("pwr_dist", C.c_int32),
+        ("gamma", C.c_double),
+        ("n_support", C.c_void_p),
+        ("support", C.c_void_p),
+        ("dual_coef", C.c_void_p),
+        ("rho", C.c_void_p),
+        ("probA", C.c_void_p),
+        ("probB", C.c_void_p),
+        ("label_map", C.c_void_p),
+        ("thresholds", C.c_void_p),
     ]
 
 
@@ -120,6 +141,12 @@ def load():
         L.wdx_dtw_matrix_dev.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_fingerprint_batch.restype = C.c_int
         L.wdx_fingerprint_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
+        L.wdx_svm_set_model.restype = C.c_int
+        L.wdx_svm_set_model.argtypes = [vp, P(SvmModelC)]
+        L.wdx_svm_predict_dev.restype = C.c_int
+        L.wdx_svm_predict_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+        L.wdx_dtw_svm_predict.restype = C.c_int
+        L.wdx_dtw_svm_predict.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_demux_batch.restype = C.c_int
         L.wdx_demux_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
         L.wdx_fingerprint_dev.restype = C.c_int

@@ -78,7 +78,9 @@ struct wdx_ctx {
     DtwRefs refs;
     Buffer refs_pad, refs_T, refs_nan;
     // host-buffer call workspaces
-    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws;
+    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws, svm_buf;
+    SvmDev svm{};
+    bool svm_set = false;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[kNumTimed];
@@ -309,7 +311,7 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf})
         b->release();
     for (int k = 0; k < kNumTimed; ++k)
         for (auto &e : ctx->pending[k]) {
@@ -623,6 +625,128 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     WDX_HIP_TRY(hipStreamSynchronize(s));
     if (R.nY == 0)
         for (int64_t r = 0; r < n_reads; ++r) call[r] = -1;
+    return WDX_SUCCESS;
+}
+
+int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!m || m->n_classes < 2 || m->n_classes > 16 || m->n_sv < 1 || m->n_train < 1 || !m->n_support ||
+        !m->support || !m->dual_coef || !m->rho || !m->probA || !m->probB || m->pwr_dist < 1) {
+        set_error("svm_set_model: need 2..16 classes, support vectors, coefficients and Platt parameters");
+        return WDX_ERR_INVALID;
+    }
+    const int k = m->n_classes, nsv = m->n_sv, np = k * (k - 1) / 2;
+    int64_t tot = 0;
+    std::vector<int32_t> start(k);
+    for (int c = 0; c < k; ++c) {
+        if (m->n_support[c] < 0) {
+            set_error("svm_set_model: negative n_support");
+            return WDX_ERR_INVALID;
+        }
+        start[c] = (int32_t)tot;
+        tot += m->n_support[c];
+    }
+    if (tot != nsv) {
+        set_error("svm_set_model: sum(n_support) != n_sv");
+        return WDX_ERR_INVALID;
+    }
+    for (int s_ = 0; s_ < nsv; ++s_)
+        if (m->support[s_] < 0 || m->support[s_] >= m->n_train) {
+            set_error("svm_set_model: support index out of range");
+            return WDX_ERR_INVALID;
+        }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    // one device block: [doubles: dual_coef | rho | probA | probB | thresholds][int32: n_support | start | support | label_map]
+    const size_t nd = (size_t)(k - 1) * nsv + 3 * (size_t)np + (size_t)k;
+    const size_t ni = 3 * (size_t)k + (size_t)nsv;
+    if ((rc = ctx->svm_buf.ensure(nd * 8 + ni * 4))) return rc;
+    std::vector<unsigned char> h(nd * 8 + ni * 4);
+    double *hd = reinterpret_cast<double *>(h.data());
+    int32_t *hi = reinterpret_cast<int32_t *>(h.data() + nd * 8);
+    size_t o = 0;
+    memcpy(hd + o, m->dual_coef, (size_t)(k - 1) * nsv * 8); o += (size_t)(k - 1) * nsv;
+    memcpy(hd + o, m->rho, (size_t)np * 8); o += np;
+    memcpy(hd + o, m->probA, (size_t)np * 8); o += np;
+    memcpy(hd + o, m->probB, (size_t)np * 8); o += np;
+    if (m->thresholds) memcpy(hd + o, m->thresholds, (size_t)k * 8);
+    memcpy(hi, m->n_support, (size_t)k * 4);
+    memcpy(hi + k, start.data(), (size_t)k * 4);
+    memcpy(hi + 2 * k, m->support, (size_t)nsv * 4);
+    if (m->label_map) memcpy(hi + 2 * k + nsv, m->label_map, (size_t)k * 4);
+    WDX_HIP_TRY(hipMemcpy(ctx->svm_buf.p, h.data(), h.size(), hipMemcpyHostToDevice));
+    const double *dd = reinterpret_cast<const double *>(ctx->svm_buf.p);
+    const int32_t *di = reinterpret_cast<const int32_t *>(reinterpret_cast<const unsigned char *>(ctx->svm_buf.p) + nd * 8);
+    SvmDev &S = ctx->svm;
+    S.dual_coef = dd;
+    S.rho = dd + (size_t)(k - 1) * nsv;
+    S.probA = S.rho + np;
+    S.probB = S.probA + np;
+    S.thresholds = m->thresholds ? S.probB + np : nullptr;
+    S.n_support = di;
+    S.start = di + k;
+    S.support = di + 2 * k;
+    S.label_map = m->label_map ? di + 2 * k + nsv : nullptr;
+    S.k = k;
+    S.n_sv = nsv;
+    S.n_train = m->n_train;
+    S.pwr = m->pwr_dist;
+    S.ngamma = (float)(-m->gamma);
+    ctx->svm_set = true;
+    return WDX_SUCCESS;
+}
+
+int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
+                        double *d_conf, void *stream) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->svm_set) {
+        set_error("no SVM model: call wdx_svm_set_model first");
+        return WDX_ERR_NO_REFS;
+    }
+    if (n < 0 || (n > 0 && !d_dist)) {
+        set_error("svm_predict_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    return launch_svm_predict(ctx->svm, d_dist, n, d_prob, d_pred, d_conf, (hipStream_t)stream);
+}
+
+int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    DtwRefs &R = ctx->refs;
+    if (R.window == 0 || !ctx->svm_set) {
+        set_error("dtw_svm_predict needs wdx_set_refs and wdx_svm_set_model first");
+        return WDX_ERR_NO_REFS;
+    }
+    if (R.nY != ctx->svm.n_train) {
+        set_error("reference set has %lld rows but the SVM was trained on %d", (long long)R.nY, ctx->svm.n_train);
+        return WDX_ERR_INVALID;
+    }
+    if (n < 0 || (n > 0 && !X)) {
+        set_error("dtw_svm_predict: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    if (n == 0) return WDX_SUCCESS;
+    hipStream_t s = nullptr;
+    const int k = ctx->svm.k;
+    const size_t xb = (size_t)(n * R.L) * 8, db = (size_t)(n * R.nY) * 4;
+    if ((rc = ctx->in0.ensure(xb))) return rc;
+    if ((rc = ctx->out0.ensure(db))) return rc;
+    if ((rc = ctx->out1.ensure((size_t)n * k * 8))) return rc;
+    if ((rc = ctx->out2.ensure((size_t)n * 4))) return rc;
+    if ((rc = ctx->out3.ensure((size_t)n * 8))) return rc;
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X, xb, hipMemcpyHostToDevice, s));
+    if ((rc = dtw_dev_locked(ctx, (const double *)ctx->in0.p, n, (float *)ctx->out0.p, nullptr, s))) return rc;
+    if ((rc = launch_svm_predict(ctx->svm, (const float *)ctx->out0.p, n, (double *)ctx->out1.p,
+                                 (int32_t *)ctx->out2.p, (double *)ctx->out3.p, s)))
+        return rc;
+    if (prob) WDX_HIP_TRY(hipMemcpyAsync(prob, ctx->out1.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, s));
+    if (pred) WDX_HIP_TRY(hipMemcpyAsync(pred, ctx->out2.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (conf) WDX_HIP_TRY(hipMemcpyAsync(conf, ctx->out3.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipStreamSynchronize(s));
     return WDX_SUCCESS;
 }
 

@@ -82,6 +82,16 @@ int launch_synth_fill(uint64_t seed, int64_t first_read, int64_t n, int32_t n_ba
                       const int32_t *dwell_table, const float *lead, const float *bc,
                       const int64_t *off, float *sig, int32_t *barcode, hipStream_t stream);
 
+// ---- SVM tail (wdx_svm.hip) -----------------------------------------------------------------------
+struct SvmDev {  // device-resident SVC(kernel="precomputed", probability=True) + label map / thresholds
+    const int32_t *n_support, *support, *start, *label_map;
+    const double *dual_coef, *rho, *probA, *probB, *thresholds;  // label_map / thresholds nullable
+    int k, n_sv, n_train, pwr;
+    float ngamma;  // -gamma rounded to float32 (NumPy: python float * float32 array -> float32)
+};
+int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
+                       double *d_conf, hipStream_t stream);
+
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream);
 
 }  // namespace wdx

@@ -1,0 +1,176 @@
+// N1: classifier tail of DTW_SVM.predict on the device --
+//   K = exp(-gamma * d^p)              /root/reference/warpdemux/models/dtw_svm.py:21-22, 90
+//   SVC.predict_proba(K)               dtw_svm.py:92  (libsvm svm_predict_probability, precomputed kernel)
+//   process_probs                      models/utils.py:45-61 (argmax, label map, top1-top2 margin, thresholds)
+// so that the (nX, nY<=3617) distance matrix never has to leave HBM.
+//
+// One 256-thread workgroup per read: kernel values of the support vectors in LDS, the k(k-1)/2
+// one-vs-one decision values by wave-level reductions, then Platt sigmoids and libsvm's pairwise-coupling
+// fixed point on one 16-lane group (k <= 16).  float64 throughout except the kernel value itself,
+// which the reference computes in float32 (np.exp of a float32 array).  Sums are tree-ordered, so
+// probabilities agree with scikit-learn to ~1e-12 given the same kernel values; expf differs from
+// NumPy's SIMD exp by <= 1 ulp(float32), i.e. ~1e-7 relative in K (tolerances in tests/).
+#include "wdx_common.h"
+
+#include <math.h>
+
+namespace wdx {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void svm_predict_kernel(SvmDev M, const float *__restrict__ dist,
+                                                          int64_t n, double *__restrict__ prob,
+                                                          int32_t *__restrict__ pred,
+                                                          double *__restrict__ conf) {
+    extern __shared__ double svm_lds[];  // kv[n_sv] | dec[npairs] | pw[k*k] | Q[k*k] | p[k] | Qp[k]
+    const int k = M.k, npairs = k * (k - 1) / 2;
+    double *kv = svm_lds;
+    double *dec = kv + M.n_sv;
+    double *pw = dec + npairs;
+    double *Q = pw + k * k;
+    volatile double *pp = Q + k * k;  // shared between the lanes of wave 0 inside the coupling loop:
+    volatile double *Qp = pp + k;     // volatile keeps every LDS access in program order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r = blockIdx.x;
+    const float *drow = dist + r * M.n_train;
+
+    // kernel values of the support vectors (float32 like the reference, then widened)
+    for (int s = tid; s < M.n_sv; s += 256) {
+        const float d = drow[M.support[s]];
+        const float t = M.pwr == 1 ? d : (M.pwr == 2 ? d * d : powf(d, (float)M.pwr));
+        kv[s] = (double)expf(M.ngamma * t);
+    }
+    __syncthreads();
+
+    // one-vs-one decision values: pair index p enumerates (i<j) row-major; waves take pairs round-robin
+    for (int p = wave; p < npairs; p += 4) {
+        int i = 0, rem = p;
+        while (rem >= k - 1 - i) {
+            rem -= k - 1 - i;
+            ++i;
+        }
+        const int j = i + 1 + rem;
+        const int si = M.start[i], sj = M.start[j], ci = M.n_support[i], cj = M.n_support[j];
+        const double *coef1 = M.dual_coef + (size_t)(j - 1) * M.n_sv, *coef2 = M.dual_coef + (size_t)i * M.n_sv;
+        double sum = 0.0;
+        for (int q = lane; q < ci; q += 64) sum += coef1[si + q] * kv[si + q];
+        for (int q = lane; q < cj; q += 64) sum += coef2[sj + q] * kv[sj + q];
+        sum = wave_sum_f64(sum);
+        if (lane == 0) dec[p] = sum - M.rho[p];
+    }
+    __syncthreads();
+
+    // Platt sigmoids -> pairwise probabilities
+    for (int p = tid; p < npairs; p += 256) {
+        int i = 0, rem = p;
+        while (rem >= k - 1 - i) {
+            rem -= k - 1 - i;
+            ++i;
+        }
+        const int j = i + 1 + rem;
+        const double fApB = dec[p] * M.probA[p] + M.probB[p];
+        double v = fApB >= 0 ? exp(-fApB) / (1.0 + exp(-fApB)) : 1.0 / (1.0 + exp(fApB));
+        v = fmin(fmax(v, 1e-7), 1.0 - 1e-7);
+        pw[i * k + j] = v;
+        pw[j * k + i] = 1.0 - v;
+    }
+    __syncthreads();
+
+    // libsvm multiclass_probability on lanes 0..k-1 of wave 0 (lane t owns row t of Q)
+    if (wave == 0) {
+        const int t = lane;
+        const bool on = t < k;
+        if (on) {
+            double qtt = 0.0;
+            for (int j = 0; j < k; ++j)
+                if (j != t) qtt += pw[j * k + t] * pw[j * k + t];
+            for (int j = 0; j < k; ++j) Q[t * k + j] = (j == t) ? qtt : -pw[j * k + t] * pw[t * k + j];
+            pp[t] = 1.0 / k;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double eps = 0.005 / k;
+        const int max_iter = k > 100 ? k : 100;
+        for (int iter = 0; iter < max_iter; ++iter) {
+            // recompute Qp and pQp (sequential order over j as in libsvm)
+            double qp = 0.0;
+            if (on)
+                for (int j = 0; j < k; ++j) qp += Q[t * k + j] * pp[j];
+            if (on) Qp[t] = qp;
+            __builtin_amdgcn_wave_barrier();
+            double pQp = 0.0;
+            for (int j = 0; j < k; ++j) pQp += pp[j] * Qp[j];  // every lane the same sum, same order
+            double err = on ? fabs(qp - pQp) : 0.0;
+            for (int off = 8; off > 0; off >>= 1) err = fmax(err, __shfl_xor(err, off));
+            err = __shfl(err, 0);
+            if (err < eps) break;
+            for (int u = 0; u < k; ++u) {
+                const double Quu = Q[u * k + u];
+                const double diff = (-Qp[u] + pQp) / Quu;
+                __builtin_amdgcn_wave_barrier();
+                if (on) {
+                    double pt = pp[t];
+                    if (t == u) pt += diff;
+                    pQp = (pQp + diff * (diff * Quu + 2 * Qp[u])) / (1 + diff) / (1 + diff);
+                    const double qpn = (Qp[t] + diff * Q[u * k + t]) / (1 + diff);
+                    pt /= (1 + diff);
+                    __builtin_amdgcn_wave_barrier();
+                    Qp[t] = qpn;
+                    pp[t] = pt;
+                } else {
+                    pQp = (pQp + diff * (diff * Quu + 2 * Qp[u])) / (1 + diff) / (1 + diff);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (on && prob) prob[r * k + t] = pp[t];
+        if (lane == 0) {
+            // process_probs: np.argmax (first maximum), margin top1 - top2, per-class threshold
+            int best = 0;
+            double b1 = pp[0], b2 = -1.0;
+            for (int j = 1; j < k; ++j) {
+                const double v = pp[j];
+                if (v > b1) {
+                    b2 = b1;
+                    b1 = v;
+                    best = j;
+                } else if (v > b2) {
+                    b2 = v;
+                }
+            }
+            const double margin = b1 - b2;
+            int label = M.label_map ? M.label_map[best] : best;
+            if (M.thresholds && margin < M.thresholds[best]) label = -1;
+            if (pred) pred[r] = label;
+            if (conf) conf[r] = margin;
+        }
+    }
+}
+
+int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
+                       double *d_conf, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    const int k = M.k;
+    const size_t lds = sizeof(double) * ((size_t)M.n_sv + (size_t)k * (k - 1) / 2 + 2 * (size_t)k * k + 2 * (size_t)k);
+    if (lds > 150 * 1024) {
+        set_error("SVM model too large for the LDS carve-up (%zu B)", lds);
+        return WDX_ERR_UNSUPPORTED;
+    }
+    WDX_HIP_TRY(hipFuncSetAttribute((const void *)svm_predict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    const int64_t slice = (1ll << 31) / 256;
+    for (int64_t base = 0; base < n; base += slice) {
+        const int64_t m = n - base < slice ? n - base : slice;
+        hipLaunchKernelGGL(svm_predict_kernel, dim3((unsigned)m), dim3(256), lds, stream, M,
+                           d_dist + base * M.n_train, m, d_prob ? d_prob + base * k : nullptr,
+                           d_pred ? d_pred + base : nullptr, d_conf ? d_conf + base : nullptr);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+}  // namespace wdx
