@@ -190,6 +190,7 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
 #define WDX_K_DTW 1
 #define WDX_K_TRANSPOSE 2
 #define WDX_K_COUNT 3
+#define WDX_K_SVM 4
 /* When enabled, every kernel launch through this context is bracketed by hipEvents on its
  * stream; wdx_kernel_time() synchronises them and returns accumulated ms and launch count. */
 int wdx_kernel_timing(wdx_ctx *ctx, int enable);

@@ -500,3 +500,26 @@ def test_dtw_svm_predict_errors_and_single_row():
     with pytest.raises(ValueError):
         m.predict(Xq)             # nproc=-1 without block_size, like the reference
     assert m.predict(Xq, nproc=1)[0].shape == (8,)
+
+
+@pytest.mark.gpu
+def test_dtw_svm_predict_reference_model_golden():
+    """g6: outputs of the reference's DTW_SVM.predict on its shipped WDX4_rna004_v1_0 model."""
+    from test_oracle_svm import load_g6
+    from warpdemux_amd.models import DTW_SVM
+
+    g, label_mapper = load_g6()
+    m = DTW_SVM(g["X_train"], g["n_support"], g["support"], g["dual_coef"], -g["intercept"], g["probA"], g["probB"],
+                label_mapper, g["thresholds"], window=int(g["window"]), penalty=float(g["penalty"]),
+                gamma=float(g["gamma"]), pwr_dist=int(g["pwr_dist"]), block_size=int(g["block_size"]))
+    pred, prob = m.predict(g["Xq"])
+    np.testing.assert_allclose(prob, g["y_prob"], rtol=0, atol=1e-5)
+    srt = np.sort(g["y_prob"], axis=1)
+    conf = srt[:, -1] - srt[:, -2]
+    safe = (conf > 1e-4) & (np.abs(conf - g["thresholds"][np.argmax(g["y_prob"], axis=1)]) > 1e-4)
+    assert safe.mean() > 0.98
+    assert np.array_equal(pred[safe], g["y_pred"][safe])
+    df = m.predict(g["Xq"], return_df=True)
+    assert list(df.columns) == list(g["df_cols"])
+    np.testing.assert_allclose(df["confidence_score"].to_numpy(), g["df_conf"], atol=1.5e-3)
+    np.testing.assert_allclose(df[[c for c in df.columns if c.startswith("p")]].to_numpy(), g["df_probs"], atol=1.5e-4)

@@ -38,3 +38,30 @@ def test_predict_proba_matches_sklearn(n_classes, n_train):
     sign = -1.0 if n_classes == 2 else 1.0   # sklearn flips the sign of the binary decision function
     np.testing.assert_allclose(dec, sign * svc.decision_function(Kq).reshape(64, -1), rtol=1e-12, atol=1e-12)
     assert np.array_equal(np.argmax(got, axis=1), np.argmax(ref, axis=1))
+
+
+def load_g6():
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_dtw_svm_wdx4.npz"))
+    label_mapper = {int(k): int(v) for k, v in zip(g["label_keys"], g["label_vals"])}
+    return g, label_mapper
+
+
+def test_oracle_matches_reference_model_golden():
+    """g6: the reference's DTW_SVM.predict on its shipped WDX4_rna004_v1_0 model (made by
+    tests/golden/make_golden_svm.py).  The oracle's tail from the stored parameters must reproduce it."""
+    g, label_mapper = load_g6()
+    D = orc.dtw_matrix(g["Xq"], g["X_train"], int(g["window"]), float(g["penalty"]))
+    K = np.exp(-float(g["gamma"]) * np.power(D, int(g["pwr_dist"])))
+    assert K.dtype == np.float32
+    prob = orc.svm_predict_proba(K, g["n_support"].astype(np.int32), g["support"].astype(np.int32), g["dual_coef"],
+                                 -g["intercept"], g["probA"], g["probB"])
+    np.testing.assert_allclose(prob, g["y_prob"], rtol=0, atol=1e-12)
+    idx = np.argmax(prob, axis=1)
+    pred = np.array([label_mapper[i] for i in idx])
+    srt = np.sort(prob, axis=1)
+    conf = srt[:, -1] - srt[:, -2]
+    pred[conf < g["thresholds"][idx]] = -1
+    assert np.array_equal(pred, g["y_pred"])
+    assert (g["y_pred"] == -1).sum() > 10 and len(np.unique(g["y_pred"])) == 5

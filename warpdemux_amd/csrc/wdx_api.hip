@@ -66,7 +66,7 @@ struct Buffer {  // grow-only device workspace
     }
 };
 
-constexpr int kNumTimed = 4;
+constexpr int kNumTimed = 5;
 
 }  // namespace wdx
 
@@ -86,8 +86,8 @@ struct wdx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[kNumTimed];
     std::vector<int64_t> pending_launches[kNumTimed];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    double acc_ms[kNumTimed] = {0, 0, 0, 0};
-    int64_t launches[kNumTimed] = {0, 0, 0, 0};
+    double acc_ms[kNumTimed] = {};
+    int64_t launches[kNumTimed] = {};
 };
 
 namespace {
@@ -709,6 +709,7 @@ int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_
         set_error("svm_predict_dev: bad arguments");
         return WDX_ERR_INVALID;
     }
+    Timed t(ctx, WDX_K_SVM, (hipStream_t)stream);
     return launch_svm_predict(ctx->svm, d_dist, n, d_prob, d_pred, d_conf, (hipStream_t)stream);
 }
 
@@ -732,20 +733,27 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
     if (n == 0) return WDX_SUCCESS;
     hipStream_t s = nullptr;
     const int k = ctx->svm.k;
-    const size_t xb = (size_t)(n * R.L) * 8, db = (size_t)(n * R.nY) * 4;
-    if ((rc = ctx->in0.ensure(xb))) return rc;
-    if ((rc = ctx->out0.ensure(db))) return rc;
-    if ((rc = ctx->out1.ensure((size_t)n * k * 8))) return rc;
-    if ((rc = ctx->out2.ensure((size_t)n * 4))) return rc;
-    if ((rc = ctx->out3.ensure((size_t)n * 8))) return rc;
-    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X, xb, hipMemcpyHostToDevice, s));
-    if ((rc = dtw_dev_locked(ctx, (const double *)ctx->in0.p, n, (float *)ctx->out0.p, nullptr, s))) return rc;
-    if ((rc = launch_svm_predict(ctx->svm, (const float *)ctx->out0.p, n, (double *)ctx->out1.p,
-                                 (int32_t *)ctx->out2.p, (double *)ctx->out3.p, s)))
-        return rc;
-    if (prob) WDX_HIP_TRY(hipMemcpyAsync(prob, ctx->out1.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, s));
-    if (pred) WDX_HIP_TRY(hipMemcpyAsync(pred, ctx->out2.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    if (conf) WDX_HIP_TRY(hipMemcpyAsync(conf, ctx->out3.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    // rows per pass: the (rows, nY) float32 distance block stays <= 1 GiB and never leaves HBM
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)1 << 30) / (4 * (int64_t)R.nY)));
+    if ((rc = ctx->in0.ensure((size_t)(chunk * R.L) * 8))) return rc;
+    if ((rc = ctx->out0.ensure((size_t)(chunk * R.nY) * 4))) return rc;
+    if ((rc = ctx->out1.ensure((size_t)chunk * k * 8))) return rc;
+    if ((rc = ctx->out2.ensure((size_t)chunk * 4))) return rc;
+    if ((rc = ctx->out3.ensure((size_t)chunk * 8))) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t m = std::min(chunk, n - r0);
+        WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X + r0 * R.L, (size_t)(m * R.L) * 8, hipMemcpyHostToDevice, s));
+        if ((rc = dtw_dev_locked(ctx, (const double *)ctx->in0.p, m, (float *)ctx->out0.p, nullptr, s))) return rc;
+        {
+            Timed t(ctx, WDX_K_SVM, s);
+            if ((rc = launch_svm_predict(ctx->svm, (const float *)ctx->out0.p, m, (double *)ctx->out1.p,
+                                         (int32_t *)ctx->out2.p, (double *)ctx->out3.p, s)))
+                return rc;
+        }
+        if (prob) WDX_HIP_TRY(hipMemcpyAsync(prob + r0 * k, ctx->out1.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, s));
+        if (pred) WDX_HIP_TRY(hipMemcpyAsync(pred + r0, ctx->out2.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        if (conf) WDX_HIP_TRY(hipMemcpyAsync(conf + r0, ctx->out3.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+    }
     WDX_HIP_TRY(hipStreamSynchronize(s));
     return WDX_SUCCESS;
 }

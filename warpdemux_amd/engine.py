@@ -120,6 +120,28 @@ class DemuxEngine:
         _lib.check(self.L.wdx_dtw_matrix_dev(self.ctx.handle, _dp(X), n, _dp(dist), _dp(am), self._stream()))
         return dist, am
 
+    # -- classifier tail -----------------------------------------------------------
+    def set_svm(self, model):
+        """``model``: a warpdemux_amd.models.DTW_SVM whose ``_X`` is the resident reference set."""
+        if model._X.shape != (self.nY, self.K):
+            raise ValueError("the SVM's training set must be the engine's reference set")
+        self._svm_model = model   # keeps the host arrays alive during the upload
+        m = model.to_c()
+        _lib.check(self.L.wdx_svm_set_model(self.ctx.handle, C.byref(m)))
+        self.n_classes = model.n_classes
+
+    def svm_predict(self, dist):
+        """(prob f64 (n,k), pred i32 (n,), conf f64 (n,)) from a device (n, nY) float32 distance matrix:
+        models/dtw_svm.py:90-93 + models/utils.py:45-61."""
+        torch = self.torch
+        n = int(dist.shape[0])
+        prob = torch.empty((n, self.n_classes), dtype=torch.float64, device=self.tdev)
+        pred = torch.empty(n, dtype=torch.int32, device=self.tdev)
+        conf = torch.empty(n, dtype=torch.float64, device=self.tdev)
+        _lib.check(self.L.wdx_svm_predict_dev(self.ctx.handle, _dp(dist), n, _dp(prob), _dp(pred), _dp(conf),
+                                              self._stream()))
+        return prob, pred, conf
+
     # -- synthetic inputs, generated in HBM ----------------------------------------------------------
     def synth_packed(self, spec: synth.SynthSpec, first_read: int, n_reads: int):
         """(sig f32[total], offsets i64[n+1], a_start i32[n], a_end i32[n], barcode i32[n]) on device,

@@ -74,6 +74,15 @@ class DTW_SVM:
     def num_bcs(self):
         return self.n_classes
 
+    def to_c(self) -> "_lib.SvmModelC":
+        """wdx_svm_model view of the host arrays (valid while ``self`` is alive)."""
+        return _lib.SvmModelC(
+            self.n_classes, int(self._support.size), int(self._X.shape[0]), self.pwr_dist, self.gamma,
+            self._n_support.ctypes.data, self._support.ctypes.data, self._dual_coef.ctypes.data,
+            self._rho.ctypes.data, self._probA.ctypes.data, self._probB.ctypes.data, self._label_arr.ctypes.data,
+            None if self.thresholds is None else self.thresholds.ctypes.data,
+        )
+
     def _ensure_resident(self):
         ctx = _lib.default_context(self._device)
         if self._uploaded_ctx is ctx:
@@ -81,12 +90,7 @@ class DTW_SVM:
         L = _lib.load()
         _lib.check(L.wdx_set_refs(ctx.handle, _lib.ptr(self._X), self._X.shape[0], self._X.shape[1],
                                   int(self.window) if self.window else 0, float(self.penalty) if self.penalty else 0.0))
-        m = _lib.SvmModelC(
-            self.n_classes, int(self._support.size), int(self._X.shape[0]), self.pwr_dist, self.gamma,
-            self._n_support.ctypes.data, self._support.ctypes.data, self._dual_coef.ctypes.data,
-            self._rho.ctypes.data, self._probA.ctypes.data, self._probB.ctypes.data, self._label_arr.ctypes.data,
-            None if self.thresholds is None else self.thresholds.ctypes.data,
-        )
+        m = self.to_c()
         _lib.check(L.wdx_svm_set_model(ctx.handle, C.byref(m)))
         self._uploaded_ctx = ctx
         return ctx
