@@ -74,7 +74,7 @@ if fast and len(sys.argv) > 3:
     print(f"ablation on {nbig} reads (ms per launch, cumulative / marginal):")
     for k in [1, 21, 22, 23, 24] + list(range(2, 10)):
         ts = []
-        for rep in range(3):
+        for rep in range(int(os.environ.get("WDX_PROF_REPS", "3"))):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _lib.check(eng.L.wdx_fingerprint_profile_dev(eng.ctx.handle, _dp(sig), _dp(off), 0, max_len, nbig, _dp(a_s),
