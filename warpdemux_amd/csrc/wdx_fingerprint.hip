@@ -836,7 +836,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const int capF = small_fast ? 4096 : 6144;
         // peak-list capacity: local maxima of the score curve run at ~N/5.6; N/4.4 leaves headroom and
         // keeps three workgroups per CU resident (a read with more peaks takes the slow path)
-        const int capP = small_fast ? 1152 : 1408;
+        int capP = small_fast ? 1152 : 1376;
+        if (const char *e = getenv("WDX_FAST_CAPP")) capP = atoi(e);  // experiment knob
         const size_t flds = fast_lds_bytes(capF, capP);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
@@ -847,6 +848,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         else kern = small_fast ? fingerprint_fast_kernel<kNptSmall, false> : fingerprint_fast_kernel<kNptLarge, false>;
         WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)flds));
+        if (getenv("WDX_DEBUG_OCC")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
+            fprintf(stderr, "[wdx] fast kernel capF=%d capP=%d lds=%zu B -> %d workgroups/CU\n", capF, capP, flds, nb);
+        }
         const int64_t slice = (1ll << 31) / FB;  // grid.x * block.x must stay below 2^32
         for (int64_t base = 0; base < n_reads; base += slice) {
             const int64_t n = n_reads - base < slice ? n_reads - base : slice;
