@@ -834,8 +834,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // windows beyond 6144 samples take the slow path
         const bool small_fast = cap <= 4096;
         const int capF = small_fast ? 4096 : 6144;
-        // peak-list capacity: local maxima of the score curve run at ~N/5.6; N/4.4 leaves headroom and
-        // keeps three workgroups per CU resident (a read with more peaks takes the slow path)
+        // peak-list capacity: local maxima of the score curve run at ~N/5.6 (>= N/5.0 observed); N/4.4
+        // leaves headroom and keeps four workgroups per CU resident at 6144 samples (five at 4096); a
+        // read with more peaks takes the slow path.  (A 5120-sample instantiation at five workgroups
+        // per CU for the 89 % of reads that fit it was measured: no gain, the kernel is issue-bound
+        // from four workgroups on.)
         int capP = small_fast ? 1152 : 1376;
         if (const char *e = getenv("WDX_FAST_CAPP")) capP = atoi(e);  // experiment knob
         const size_t flds = fast_lds_bytes(capF, capP);
