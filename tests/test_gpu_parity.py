@@ -523,3 +523,59 @@ def test_dtw_svm_predict_reference_model_golden():
     assert list(df.columns) == list(g["df_cols"])
     np.testing.assert_allclose(df["confidence_score"].to_numpy(), g["df_conf"], atol=1.5e-3)
     np.testing.assert_allclose(df[[c for c in df.columns if c.startswith("p")]].to_numpy(), g["df_probs"], atol=1.5e-4)
+
+
+@pytest.mark.gpu
+def test_full_size_properties_one_million_reads():
+    """BASELINE config 2 scale (1 M synthetic reads, fused path), through properties that do not need the
+    oracle at that size: run-to-run determinism, shard invariance (any split of the reads gives the same
+    per-read results and the same count histogram -- what the multi-GPU sharding relies on), a checksum of
+    the histogram, agreement of the calls with the generator's true barcodes, and oracle parity on a
+    random sample of the 1 M."""
+    import torch
+
+    from bench import make_refs
+    from warpdemux_amd.engine import DemuxEngine
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K, n = 110, 1_000_000
+    refs = make_refs(synth.SynthSpec(n_barcodes=10, noise_sigma=0.25, spikes=False), synth, sig_proc)
+    eng = DemuxEngine(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, n)
+    r1 = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, want_fpt=True)
+    r2 = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, want_fpt=True)
+    torch.cuda.synchronize()
+    for a, b in ((r1.call, r2.call), (r1.status, r2.status), (r1.counts, r2.counts)):
+        assert torch.equal(a, b)
+    assert torch.equal(r1.dist.view(torch.int32), r2.dist.view(torch.int32))
+    assert torch.equal(r1.fpt.view(torch.int64), r2.fpt.view(torch.int64))
+    counts = r1.counts.cpu().numpy()
+    assert counts.sum() == n and counts[-1] == int((r1.status != 0).sum())
+    # shards: three uneven contiguous pieces, accumulated into one histogram
+    acc = torch.zeros_like(r1.counts)
+    cuts = [0, 333_333, 900_001, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        o = off[lo:hi + 1] - off[lo]
+        s = sig[int(off[lo]):int(off[hi])]
+        rs = eng.demux(s, a_s[lo:hi], a_e[lo:hi], offsets=o.contiguous(), max_len=max_len, counts=acc)
+        assert torch.equal(rs.call, r1.call[lo:hi]) and torch.equal(rs.status, r1.status[lo:hi])
+        assert torch.equal(rs.dist.view(torch.int32), r1.dist[lo:hi].view(torch.int32))
+    assert torch.equal(acc, r1.counts)
+    # the calls mostly recover the generator's barcodes (sanity only)
+    ok = r1.status == 0
+    assert ok.float().mean().item() > 0.999
+    assert (r1.call[ok] == bc[ok]).float().mean().item() > 0.75   # nearest single template, noisy synthetic barcodes
+    # oracle parity on 400 reads drawn from all over the batch
+    rng = np.random.default_rng(7)
+    idx = np.sort(rng.choice(n, 400, replace=False))
+    off_h, a_s_h, a_e_h = off.cpu().numpy(), a_s.cpu().numpy(), a_e.cpu().numpy()
+    po = orc.SegParams(barcode_num_events=K)
+    fpt_g, dist_g, call_g = r1.fpt.cpu().numpy(), r1.dist.cpu().numpy(), r1.call.cpu().numpy()
+    for i in idx:
+        row = sig[int(off_h[i]):int(off_h[i + 1])].cpu().numpy()
+        o = orc.fingerprint_one(row, a_s_h[i], a_e_h[i], po)
+        assert o["status"] == int(r1.status[i])
+        if o["status"] == 0:
+            assert np.array_equal(fpt_g[i], o["fpt"])
+            D = orc.dtw_matrix(o["fpt"][None, :], refs, 15, 0.1)
+            assert np.array_equal(dist_g[i], D[0]) and call_g[i] == int(np.argmin(D[0]))
