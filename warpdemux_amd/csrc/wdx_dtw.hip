@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <utility>
 
 namespace wdx {
 
@@ -127,6 +128,70 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
         double res = sqrt(r[W - 1]);
         if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
         float f = (float)res;
+        if (active) out[a * sA + (int64_t)b * sB] = f;
+        acc.push(f, b);
+    }
+    if (argmin && active) argmin[a] = acc.idx;
+}
+
+// Short series, fully unrolled (the shipped DTW_SVM models: 25-point fingerprints, window 15, penalty 0.1
+// -- every model under warpdemux/models/model_files/).  One lane per query series, the DP column
+// vector D[L] and the query x[L] in registers, the reference uniform across the wave (scalar loads);
+// rows and columns are compile-time, so the band limits cost nothing and only cells inside the band
+// are computed (515 of the 725 that the rolling-band kernel evaluates for L = 25, all of them with
+// masks there).  Same float64 operations per cell as dtw_row -> identical bits.
+// row I of the short-series DP; everything about the band is a compile-time constant
+template <int L, int W, int I>
+__device__ __forceinline__ void dtw_short_row(double (&D)[L], const double xi, const double *__restrict__ y,
+                                              const double p2) {
+    constexpr int jlo = I - (W - 1) > 0 ? I - (W - 1) : 0;
+    constexpr int jhi = I + (W - 1) < L - 1 ? I + (W - 1) : L - 1;
+    double left = WDX_INF;
+    double diag = jlo == 0 ? (I == 0 ? 0.0 : WDX_INF) : D[jlo > 0 ? jlo - 1 : 0];
+#pragma unroll
+    for (int j = jlo; j <= jhi; ++j) {
+        const double up = D[j];
+        double d = xi - y[j];
+        d = d * d;
+        double t = (j == jlo ? up : min_f64(up, left)) + p2;
+        t = min_f64(t, diag);
+        const double v = d + t;
+        diag = up;
+        D[j] = v;
+        left = v;
+    }
+}
+template <int L, int W, int... Is>
+__device__ __forceinline__ void dtw_short_rows(double (&D)[L], const double (&x)[L], const double *__restrict__ y,
+                                               const double p2, std::integer_sequence<int, Is...>) {
+    (dtw_short_row<L, W, Is>(D, x[Is], y, p2), ...);
+}
+
+template <int L, int W>
+__global__ __launch_bounds__(64) void dtw_short_kernel(
+    const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
+    const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
+    const uint8_t *__restrict__ b_nan, double p2, float *__restrict__ out, int64_t sA, int64_t sB,
+    int32_t *__restrict__ argmin, int refs_per_block) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = a < nA;
+    const int64_t al = active ? a : nA - 1;
+    const int b0 = blockIdx.y * refs_per_block;
+    const int b1 = min(nB, b0 + refs_per_block);
+    const bool anan = a_nan ? (a_nan[al] != 0) : false;
+    double x[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) x[i] = AT[(int64_t)i * ldA + al];
+    ArgminAcc acc;
+    for (int b = b0; b < b1; ++b) {
+        const double *__restrict__ y = Bpad + (int64_t)b * Lpad + halo;
+        double D[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
+        dtw_short_rows<L, W>(D, x, y, p2, std::make_integer_sequence<int, L>{});
+        double res = sqrt(D[L - 1]);
+        if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
+        const float f = (float)res;
         if (active) out[a * sA + (int64_t)b * sB] = f;
         acc.push(f, b);
     }
@@ -342,6 +407,13 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
         return WDX_ERR_INVALID;
     }
     dim3 grid((unsigned)gx, (unsigned)((nB + rpb - 1) / rpb));
+    if (L == 25 && w == 15 && !getenv("WDX_DTW_NO_SHORT")) {
+        hipLaunchKernelGGL((dtw_short_kernel<25, 15>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad, Lpad,
+                           halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
+        WDX_HIP_TRY(hipGetLastError());
+        if (d_argmin && !fused_argmin) return launch_argmin(out, nA, nB, d_argmin, stream);
+        return WDX_SUCCESS;
+    }
 #define WDX_LAUNCH_BAND(WW, EX)                                                                   \
     hipLaunchKernelGGL((dtw_band_kernel<WW, EX>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, \
                        Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB, fused_argmin, rpb)
