@@ -56,6 +56,40 @@ __device__ __forceinline__ void dtw_row(double (&r)[2 * W - 1], double x,
     }
 }
 
+// dtw_row with a compile-time range [CLO, CHI] of band cells that lie inside the matrix: the head and tail
+// rows of the band without masks, and without touching the cells outside (head: they stay +inf; tail:
+// they go stale but are never read again).
+template <int W, int CLO, int CHI>
+__device__ __forceinline__ void dtw_row_ct(double (&r)[2 * W - 1], double x, const double *__restrict__ yi,
+                                           double p2) {
+    constexpr int B = 2 * W - 1;
+    double left = WDX_INF;
+#pragma unroll
+    for (int c = CLO; c <= CHI; ++c) {
+        double d = x - yi[c];
+        d = d * d;
+        const double up = (c + 1 < B) ? r[c + 1 < B ? c + 1 : 0] : WDX_INF;
+        double t = (c == CLO ? up : min_f64(up, left)) + p2;
+        t = min_f64(t, r[c]);
+        const double v = d + t;
+        r[c] = v;
+        left = v;
+    }
+}
+// head rows i = 0 .. W-2 (band cells c >= W-1-i), tail rows i = L-W+1+t, t = 0 .. W-2 (c <= 2W-3-t)
+template <int W, int... Is>
+__device__ __forceinline__ void dtw_head_rows(double (&r)[2 * W - 1], const double *__restrict__ xp, int64_t ldA,
+                                              const double *__restrict__ y, double p2,
+                                              std::integer_sequence<int, Is...>) {
+    (dtw_row_ct<W, W - 1 - Is, 2 * W - 2>(r, xp[(int64_t)Is * ldA], y + Is, p2), ...);
+}
+template <int W, int... Ts>
+__device__ __forceinline__ void dtw_tail_rows(double (&r)[2 * W - 1], const double *__restrict__ xp, int64_t ldA,
+                                              const double *__restrict__ y, double p2, int i0,
+                                              std::integer_sequence<int, Ts...>) {
+    (dtw_row_ct<W, 0, 2 * W - 3 - Ts>(r, xp[(int64_t)(i0 + Ts) * ldA], y + i0 + Ts, p2), ...);
+}
+
 // np.argmin running update on float32 values (first minimum; first NaN wins outright)
 struct ArgminAcc {
     float best = __builtin_huge_valf();
@@ -99,7 +133,18 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
         r[W - 1] = 0.0;
         double xn = xp[0];
         int i = 0;
-        if (EXACT_W) {
+        if (EXACT_W && L >= 2 * (W - 1)) {
+            // head and tail rows from templates (no masks, no cells outside the matrix); loads of x are
+            // independent of the recurrence and get hoisted by the compiler
+            dtw_head_rows<W>(r, xp, ldA, y, p2, std::make_integer_sequence<int, W - 1>{});
+            xn = xp[(int64_t)(W - 1) * ldA];
+            for (i = W - 1; i < L - W + 1; ++i) {
+                const double x = xn;
+                xn = xp[(int64_t)(i + 1) * ldA];  // i + 1 <= L - W + 1 < L
+                dtw_row<W, false>(r, x, y + i, p2, 0, 0, 0);
+            }
+            dtw_tail_rows<W>(r, xp, ldA, y, p2, L - W + 1, std::make_integer_sequence<int, W - 1>{});
+        } else if (EXACT_W) {
             const int head_end = min(W - 1, L);          // rows whose band leaves [0, L)
             const int body_end = max(head_end, L - W + 1);
             for (; i < head_end; ++i) {
