@@ -579,3 +579,32 @@ def test_full_size_properties_one_million_reads():
             assert np.array_equal(fpt_g[i], o["fpt"])
             D = orc.dtw_matrix(o["fpt"][None, :], refs, 15, 0.1)
             assert np.array_equal(dist_g[i], D[0]) and call_g[i] == int(np.argmin(D[0]))
+
+
+@pytest.mark.gpu
+def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch):
+    """Adapter windows of 6145..8192 samples are listed on the device by the 6144-sample fast kernel and
+    retried by the 8192-sample one; longer ones (<= 11200) take the exact path.  All three must agree with
+    the oracle bit for bit, in one mixed batch."""
+    rng = np.random.default_rng(21)
+    lens = [5000, 6144, 6145, 6500, 7000, 7777, 8191, 8192, 8193, 9000, 4000, 6300] * 8
+    n, stride = len(lens), 9200
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, ln in enumerate(lens):
+        ev = rng.integers(20, 60)
+        lvl = np.repeat(rng.normal(80, 15, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = np.round((lvl + rng.normal(0, 2, ln)) * 8) / 8   # quantised like ADC counts
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array(lens, dtype=np.int32)
+    for K, seg_norm in ((25, "mean"), (110, "median")):
+        ph = sig_proc.SegParams(padding=0, barcode_num_events=K, seg_norm=seg_norm)
+        po = orc.SegParams(padding=0, barcode_num_events=K, seg_norm=seg_norm)
+        monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+        monkeypatch.setenv("WDX_FORCE_SLOW", "1")
+        sl = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+        monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
+        assert np.array_equal(fb.status, status) and np.array_equal(sl.status, status) and (status == 0).all()
+        assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats)
+        assert _same(sl.fpt, fpt) and _same(sl.dwell, dwell) and _same(sl.stats, stats)

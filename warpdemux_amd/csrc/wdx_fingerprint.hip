@@ -775,7 +775,7 @@ static int launch_fp_list(const FpArgs &A, size_t lds, const unsigned *count, co
     return WDX_SUCCESS;
 }
 
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 4 * (n_reads > 0 ? n_reads : 0); }
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 8 * (n_reads > 0 ? n_reads : 0); }
 
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
@@ -842,10 +842,15 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         int capP = small_fast ? 1152 : 1376;
         if (const char *e = getenv("WDX_FAST_CAPP")) capP = atoi(e);  // experiment knob
         const size_t flds = fast_lds_bytes(capF, capP);
-        unsigned *count = reinterpret_cast<unsigned *>(d_ws);
+        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow list, [1] big list
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
+        int32_t *big = list + n_reads;
         WDX_HIP_TRY(hipMemsetAsync(count, 0, 16, stream));
-        FastArgs F{A, capF, capP, count, list};
+        // windows of 6145..8192 samples (and reads whose peak lists overflow) are listed on the device and
+        // retried by an 8192-sample instantiation (three workgroups per CU) before anything takes the
+        // exact slow path; only launched when the batch can contain such windows
+        const bool with_big = !small_fast && cap > 6144 && !(d_prof && stop_phase > 0);
+        FastArgs F{A, capF, capP, count, list, with_big ? count + 1 : nullptr, with_big ? big : nullptr, nullptr, nullptr};
         void (*kern)(FastArgs) = nullptr;
         if (d_prof) kern = small_fast ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptLarge, true>;
         else kern = small_fast ? fingerprint_fast_kernel<kNptSmall, false> : fingerprint_fast_kernel<kNptLarge, false>;
@@ -862,6 +867,16 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             F.a.block_base = base;
             hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(FB), flds, stream, F);
             if (n_launches) ++*n_launches;
+        }
+        if (with_big) {
+            const int capF2 = 8192, capP2 = 1856;
+            const size_t flds2 = fast_lds_bytes(capF2, capP2);
+            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big};
+            WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_fast_list_kernel<kNptHuge>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
+            const int64_t grid = n_reads < 1024 ? n_reads : 1024;
+            hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2, stream,
+                               F2);
         }
         WDX_HIP_TRY(hipGetLastError());
         return small ? launch_fp_list<512>(A, lds, count, list, stream)
