@@ -13,6 +13,7 @@
 #include "wdx_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace wdx {
 
@@ -151,10 +152,186 @@ __global__ __launch_bounds__(256) void svm_predict_kernel(SvmDev M, const float 
     }
 }
 
+// ---- matrix-core variant (k <= 17) ---------------------------------------------------------------
+// The decision values are a dense contraction: for class c and coefficient row q,
+//   P[r][q][c] = sum over the support vectors s of class c of dual_coef[q][s] * K[r][s],
+// and the one-vs-one value of the pair (i < j) is P[j-1][i] + P[i][j] - rho.  One wave takes 16 reads:
+// A = kernel values (16 reads x 4 support vectors, made on the fly: one float32 exp per lane and step),
+// B = dual_coef^T (4 support vectors x 16 rows, zero-padded), v_mfma_f64_16x16x4_f64 accumulates class by
+// class, so dual_coef is streamed once per 16 reads instead of once per read and every kernel value is
+// computed exactly once.  Each accumulator entry belongs to exactly one pair; the two contributions of a
+// pair arrive in different class passes of the same wave, so they are added into LDS without atomics.
+// Platt + coupling then run as in svm_predict_kernel, four reads at a time on the wave's four 16-lane
+// groups.  (Summation order differs from libsvm's; the float32 kernel values bound the agreement with
+// scikit-learn at ~1e-7 relative anyway, tolerances in tests/.)
+typedef double wdx_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const float *__restrict__ dist,
+                                                              int64_t n, double *__restrict__ prob,
+                                                              int32_t *__restrict__ pred,
+                                                              double *__restrict__ conf) {
+    extern __shared__ double svm_lds[];  // dec[16][npairs] | 4 x (pw[k*k] | Q[k*k] | p[k] | Qp[k])
+    const int k = M.k, npairs = k * (k - 1) / 2;
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
+    double *dec = svm_lds;
+    const int grp_doubles = 2 * k * k + 2 * k;
+    double *grp_base = dec + 16 * npairs;
+
+    for (int idx = lane; idx < 16 * npairs; idx += 64) dec[idx] = -M.rho[idx % npairs];
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 1: decision values through the matrix cores
+    {
+        const int ar = lane & 15, kk = lane >> 4;  // A: read ar, B: coefficient row ar; both: support vector kk of the step
+        const int64_t rr = r0 + ar < n ? r0 + ar : n - 1;
+        const float *drow = dist + rr * M.n_train;
+        const bool qrow = ar < k - 1;
+        const double *crow = M.dual_coef + (size_t)(qrow ? ar : 0) * M.n_sv;
+        for (int c = 0; c < k; ++c) {
+            const int s0 = M.start[c], cn = M.n_support[c];
+            wdx_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int t = 0; t < cn; t += 4) {
+                const int s = s0 + t + kk;
+                const bool ok = t + kk < cn;
+                const int sc = ok ? s : s0;
+                const float d = drow[M.support[sc]];
+                const float tt = M.pwr == 1 ? d : (M.pwr == 2 ? d * d : powf(d, (float)M.pwr));
+                const double a = ok ? (double)expf(M.ngamma * tt) : 0.0;
+                const double b = (ok && qrow) ? crow[sc] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            // acc[reg] = P[read kk + 4 reg][q = ar][c]  ->  its pair
+            if (qrow) {
+                const int q = ar;
+                const int i = q < c ? q : c, j = q < c ? c : q + 1;
+                const int p = i * (k - 1) - i * (i - 1) / 2 + (j - i - 1);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dec[(kk + 4 * reg) * npairs + p] += acc[reg];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // ---- phase 2: Platt sigmoids + libsvm's pairwise coupling, four reads at a time (16 lanes each)
+    const int g = lane >> 4, t = lane & 15;
+    double *pw = grp_base + g * grp_doubles;
+    double *Q = pw + k * k;
+    volatile double *pp = Q + k * k;
+    volatile double *Qp = pp + k;
+    const bool on = t < k;
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const int rl = rnd * 4 + g;  // read of this group within the tile
+        const int64_t r = r0 + rl;
+        const double *dr = dec + rl * npairs;
+        for (int p = t; p < npairs; p += 16) {
+            int i = 0, rem = p;
+            while (rem >= k - 1 - i) {
+                rem -= k - 1 - i;
+                ++i;
+            }
+            const int j = i + 1 + rem;
+            const double fApB = dr[p] * M.probA[p] + M.probB[p];
+            double v = fApB >= 0 ? exp(-fApB) / (1.0 + exp(-fApB)) : 1.0 / (1.0 + exp(fApB));
+            v = fmin(fmax(v, 1e-7), 1.0 - 1e-7);
+            pw[i * k + j] = v;
+            pw[j * k + i] = 1.0 - v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (on) {
+            double qtt = 0.0;
+            for (int j = 0; j < k; ++j)
+                if (j != t) qtt += pw[j * k + t] * pw[j * k + t];
+            for (int j = 0; j < k; ++j) Q[t * k + j] = (j == t) ? qtt : -pw[j * k + t] * pw[t * k + j];
+            pp[t] = 1.0 / k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double eps = 0.005 / k;
+        const int max_iter = k > 100 ? k : 100;
+        bool live = true;  // per 16-lane group; the wave keeps sweeping until every group has converged
+        for (int iter = 0; iter < max_iter; ++iter) {
+            double qp = 0.0;
+            if (on)
+                for (int j = 0; j < k; ++j) qp += Q[t * k + j] * pp[j];
+            if (on && live) Qp[t] = qp;
+            __builtin_amdgcn_wave_barrier();
+            double pQp = 0.0;
+            for (int j = 0; j < k; ++j) pQp += pp[j] * Qp[j];
+            double err = on ? fabs(qp - pQp) : 0.0;
+            for (int off = 8; off > 0; off >>= 1) err = fmax(err, __shfl_xor(err, off));
+            if (err < eps) live = false;
+            if (!__ballot(live)) break;
+            for (int u = 0; u < k; ++u) {
+                const double Quu = Q[u * k + u];
+                const double diff = (-Qp[u] + pQp) / Quu;
+                __builtin_amdgcn_wave_barrier();
+                double pt = 0.0, qpn = 0.0;
+                if (on) {
+                    pt = pp[t];
+                    if (t == u) pt += diff;
+                    qpn = (Qp[t] + diff * Q[u * k + t]) / (1 + diff);
+                    pt /= (1 + diff);
+                }
+                pQp = (pQp + diff * (diff * Quu + 2 * Qp[u])) / (1 + diff) / (1 + diff);
+                __builtin_amdgcn_wave_barrier();
+                if (on && live) {
+                    Qp[t] = qpn;
+                    pp[t] = pt;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (r < n) {
+            if (on && prob) prob[r * k + t] = pp[t];
+            if (t == 0) {
+                int best = 0;
+                double b1 = pp[0], b2 = -1.0;
+                for (int j = 1; j < k; ++j) {
+                    const double v = pp[j];
+                    if (v > b1) {
+                        b2 = b1;
+                        b1 = v;
+                        best = j;
+                    } else if (v > b2) {
+                        b2 = v;
+                    }
+                }
+                const double margin = b1 - b2;
+                int label = M.label_map ? M.label_map[best] : best;
+                if (M.thresholds && margin < M.thresholds[best]) label = -1;
+                if (pred) pred[r] = label;
+                if (conf) conf[r] = margin;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                        double *d_conf, hipStream_t stream) {
     if (n == 0) return WDX_SUCCESS;
     const int k = M.k;
+    if (k >= 2 && k <= 17 && !getenv("WDX_SVM_NO_MFMA")) {
+        const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (2 * (size_t)k * k + 2 * (size_t)k));
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)svm_predict_mfma_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const int64_t tiles = (n + 15) / 16;
+        const int64_t slice = (1ll << 31) / 64;
+        for (int64_t base = 0; base < tiles; base += slice) {
+            const int64_t m = tiles - base < slice ? tiles - base : slice;
+            const int64_t rb = base * 16, rn = n - rb < m * 16 ? n - rb : m * 16;
+            hipLaunchKernelGGL(svm_predict_mfma_kernel, dim3((unsigned)m), dim3(64), lds2, stream, M,
+                               d_dist + rb * M.n_train, rn, d_prob ? d_prob + rb * k : nullptr,
+                               d_pred ? d_pred + rb : nullptr, d_conf ? d_conf + rb : nullptr);
+        }
+        WDX_HIP_TRY(hipGetLastError());
+        return WDX_SUCCESS;
+    }
     const size_t lds = sizeof(double) * ((size_t)M.n_sv + (size_t)k * (k - 1) / 2 + 2 * (size_t)k * k + 2 * (size_t)k);
     if (lds > 150 * 1024) {
         set_error("SVM model too large for the LDS carve-up (%zu B)", lds);
