@@ -242,6 +242,14 @@ def main():
     except (OSError, ValueError):
         pass
 
+    valu_busy = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01e_sq_counters.json")) as fh:
+            pl = json.load(fh)["kernels"][dom.split("<")[0]]["per_launch"]
+        valu_busy = pl["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pl["GRBM_GUI_ACTIVE"] / 8.0)
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = None
     if rank == 0:
         reads_total = n_reads * world
@@ -280,10 +288,12 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": dom_n,
+                # what actually bounds the kernel (float64 VALU issue), from the committed PMC pass
+                "valu_busy_frac": valu_busy,
             },
-            "kernels_ms_per_step": {
-                "fingerprint": fp_ms / max(fp_n, 1), "dtw": dtw_ms / max(dtw_n, 1),
-                "transpose": tr_ms / max(tr_n, 1), "count": cnt_ms / max(cnt_n, 1),
+            "kernels_ms_per_step": {   # HIP-event sums over all launches of a step (a step may be sliced)
+                "fingerprint": fp_ms / max(args.steps, 1), "dtw": dtw_ms / max(args.steps, 1),
+                "transpose": tr_ms / max(args.steps, 1), "count": cnt_ms / max(args.steps, 1),
             },
             "fused_path": {
                 "algorithmic_bytes_per_read": fused_bytes_per_read,
