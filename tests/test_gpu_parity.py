@@ -608,3 +608,59 @@ def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch)
         assert np.array_equal(fb.status, status) and np.array_equal(sl.status, status) and (status == 0).all()
         assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats)
         assert _same(sl.fpt, fpt) and _same(sl.dwell, dwell) and _same(sl.stats, stats)
+
+
+def _styled_signal(rng, ln, style):
+    ev = int(rng.integers(12, 70))
+    lvl = np.repeat(rng.normal(90, 18, ln // ev + 2), ev)[:ln]
+    x = lvl + rng.normal(0, rng.uniform(0.5, 4.0), ln)
+    if style == "quantised":
+        x = np.round(x * 5.8) / 5.8 + 0.37
+    elif style == "integers":
+        x = np.round(x)
+    elif style == "heavy":
+        x = x + rng.standard_t(2, ln) * 3
+    elif style == "negative":
+        x = x - 95.0
+    elif style == "spiky":
+        k = rng.integers(0, ln, 25)
+        x[k] += rng.choice([-1, 1], 25) * rng.uniform(60, 400, 25)
+    elif style == "flat_runs":
+        for _ in range(6):
+            a = int(rng.integers(0, ln - 200))
+            x[a:a + int(rng.integers(15, 180))] = x[a]
+    elif style == "clipped_low":
+        x = np.maximum(x, np.percentile(x, 30))
+    return x.astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_fingerprint_randomised_configs_and_signal_styles(seed):
+    """Random segmentation parameters x signal styles (quantised, integer-valued, heavy-tailed, negative,
+    spiky, flat runs, low-clipped) x window lengths on both sides of every fast-path capacity: GPU == oracle,
+    bit for bit, whichever kernel a read ends up in."""
+    rng = np.random.default_rng(1000 + seed)
+    styles = ["gauss", "quantised", "integers", "heavy", "negative", "spiky", "flat_runs", "clipped_low"]
+    n, stride = 96, 9100
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        ln = int(rng.choice([300, 900, 1400, 2500, 4000, 4100, 5000, 6100, 6200, 7000, 8150, 8250, 8900]))
+        ln += int(rng.integers(-40, 40))
+        st = int(rng.integers(0, 60))
+        mb[i, :st + ln + 50] = _styled_signal(rng, st + ln + 50, styles[i % len(styles)])
+        a_s[i], a_e[i] = st, st + ln
+    ok = (rng.uniform(size=n) > 0.04).astype(np.uint8)
+    kw = dict(padding=int(rng.choice([0, 30, 100])), outlier_thresh=float(rng.choice([3.0, 5.0, 8.0])),
+              num_events=int(rng.choice([60, 110, 120])), min_obs_per_base=int(rng.choice([2, 3, 6, 9])),
+              running_stat_width=int(rng.choice([12, 12, 12, 10, 18])),
+              seg_norm=str(rng.choice(["mean", "median", "none"])))
+    kw["barcode_num_events"] = int(rng.choice([10, 25, kw["num_events"]]))
+    ph, po = sig_proc.SegParams(**kw), orc.SegParams(**kw)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph, success=ok)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po, ok=ok)
+    assert np.array_equal(fb.status, status), (kw, np.flatnonzero(fb.status != status))
+    assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats), kw
+    assert (status == 0).sum() > n // 3
