@@ -95,6 +95,11 @@ int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, i
  * Y is a HOST pointer; it is re-uploaded only if its content/params differ from the cached set. */
 int wdx_set_refs(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
                  double penalty);
+/* Counter that changes whenever the resident reference set changes (samples, window or penalty) -- by
+ * wdx_set_refs or by wdx_dtw_matrix, which installs its Y.  A caller that keeps "its" references resident
+ * across calls (the live tick loop, worker.py:26-131) compares it with the value it saw after its own
+ * wdx_set_refs to learn that another user of the context has replaced them. */
+int wdx_refs_generation(wdx_ctx *ctx, int64_t *generation);
 
 /* Device-resident DTW against the resident reference set.
  * dX: (nX,L) float64 row-major DEVICE; d_out: (nX,nY) float32 DEVICE;

@@ -329,6 +329,12 @@ def test_fused_host_call_matches_separate_calls():
         assert _same(D, orc.dtw_matrix(fb.fpt[good], Y, 15, 0.1))
     with pytest.raises(ValueError):
         sig_proc.demux_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=24), n_refs=nY)
+    # another user of the context replaces the resident references (same shape, other content): the tick
+    # loop's references come back by themselves
+    before = sig_proc.demux_batch(mb, a_s, a_e, p, success=ok, n_refs=nY)
+    pdist.distance_matrix_to(fb.fpt[good][:3], Y[::-1].copy(), window=15, penalty=0.1, n_jobs=1)
+    after = sig_proc.demux_batch(mb, a_s, a_e, p, success=ok, n_refs=nY)
+    assert _same(before.dist, after.dist) and np.array_equal(before.call, after.call)
 
 
 def test_detect_results_to_fpt_shim():
@@ -447,7 +453,8 @@ def _reference_tail(svc, Xtr, Xq, label_mapper, thr):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_classes,n_train,thresholds", [(2, 80, False), (3, 150, True), (5, 300, True),
-                                                          (11, 500, False), (12, 700, True)])
+                                                          (11, 500, False), (12, 700, True),
+                                                          (16, 800, True)])    # largest supported model
 def test_dtw_svm_predict_matches_sklearn(n_classes, n_train, thresholds):
     sklearn = pytest.importorskip("sklearn")
     svc, Xtr, Xq, label_mapper, thr, m = _svm_case(n_classes, n_train, 333, seed=n_classes, thresholds=thresholds)
@@ -499,6 +506,22 @@ def test_dtw_svm_predict_errors_and_single_row():
     m.block_size = None
     with pytest.raises(ValueError):
         m.predict(Xq)             # nproc=-1 without block_size, like the reference
+    # engine limit: at most 16 classes (the coupling runs on 16-lane groups)
+    from warpdemux_amd.models import DTW_SVM
+    k = 17
+    big = DTW_SVM(np.zeros((k, 25)), np.ones(k, dtype=np.int32), np.arange(k, dtype=np.int32), np.zeros((k - 1, k)),
+                  np.zeros(k * (k - 1) // 2), np.zeros(k * (k - 1) // 2), np.zeros(k * (k - 1) // 2),
+                  {i: i for i in range(k)}, None, window=15, penalty=0.1, block_size=100)
+    with pytest.raises(ValueError):
+        big.predict(np.zeros((2, 25)))
+    # the context holds one reference set / one model at a time: interleaved users must not see each other's
+    svc2, Xtr2, Xq2, lm2, thr2, m2 = _svm_case(3, 150, 8, seed=5)
+    ref1 = m.predict(Xq, nproc=1)
+    ref2 = m2.predict(Xq2, nproc=1)
+    pdist.distance_matrix_to(Xq, np.flipud(Xtr2), window=15, penalty=0.1, n_jobs=1)   # same shape, other content
+    again1, again2 = m.predict(Xq, nproc=1), m2.predict(Xq2, nproc=1)
+    assert np.array_equal(ref1[0], again1[0]) and np.array_equal(ref1[1], again1[1])
+    assert np.array_equal(ref2[0], again2[0]) and np.array_equal(ref2[1], again2[1])
     assert m.predict(Xq, nproc=1)[0].shape == (8,)
 
 

@@ -29,7 +29,7 @@ NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 # every symbol include/wdx.h declares (tests check the .so exports each of them)
 EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
-    "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_dtw_matrix_dev",
+    "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
     "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
@@ -135,6 +135,8 @@ def load():
         L.wdx_ctx_synchronize.argtypes = [vp, vp]
         L.wdx_dtw_matrix.restype = C.c_int
         L.wdx_dtw_matrix.argtypes = [vp, vp, i64, vp, i64, i64, i32, f64, vp, vp]
+        L.wdx_refs_generation.restype = C.c_int
+        L.wdx_refs_generation.argtypes = [vp, P(C.c_int64)]
         L.wdx_set_refs.restype = C.c_int
         L.wdx_set_refs.argtypes = [vp, vp, i64, i64, i32, f64]
         L.wdx_dtw_matrix_dev.restype = C.c_int

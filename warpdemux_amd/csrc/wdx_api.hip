@@ -79,6 +79,7 @@ struct wdx_ctx {
     Buffer refs_pad, refs_T, refs_nan;
     // host-buffer call workspaces
     Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws, svm_buf;
+    int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes
     SvmDev svm{};
     bool svm_set = false;
     // timing
@@ -147,10 +148,12 @@ int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_
     h = fnv1a(&L, sizeof(L), h);
     DtwRefs &R = ctx->refs;
     if (R.window != 0 && R.content_hash == h && R.nY == nY && R.L == L) {
+        if (R.window != w_eff || R.penalty != penalty) ++ctx->refs_gen;
         R.window = w_eff;  // same samples: only the scalars may have changed
         R.penalty = penalty;
         return WDX_SUCCESS;
     }
+    ++ctx->refs_gen;
     const int halo = kMaxRegWindow - 1;
     const int64_t Lpad = L + 2 * halo;
     const int64_t ldT = round_up(nY > 0 ? nY : 1, 64);
@@ -329,6 +332,18 @@ int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream) {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return WDX_SUCCESS;
+}
+
+int wdx_refs_generation(wdx_ctx *ctx, int64_t *generation) {
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!generation) {
+        set_error("refs_generation: null output");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *generation = ctx->refs_gen;
     return WDX_SUCCESS;
 }
 

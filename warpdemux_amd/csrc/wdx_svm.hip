@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void svm_predict_kernel(SvmDev M, const float 
     }
 }
 
-// ---- matrix-core variant (k <= 17) ---------------------------------------------------------------
+// ---- matrix-core variant (every supported model: k <= 16) ---------------------------------------------------------------
 // The decision values are a dense contraction: for class c and coefficient row q,
 //   P[r][q][c] = sum over the support vectors s of class c of dual_coef[q][s] * K[r][s],
 // and the one-vs-one value of the pair (i < j) is P[j-1][i] + P[i][j] - rho.  One wave takes 16 reads:
@@ -316,7 +316,7 @@ int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *
                        double *d_conf, hipStream_t stream) {
     if (n == 0) return WDX_SUCCESS;
     const int k = M.k;
-    if (k >= 2 && k <= 17 && !getenv("WDX_SVM_NO_MFMA")) {
+    if (k >= 2 && k <= 16 && !getenv("WDX_SVM_NO_MFMA")) {
         const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (2 * (size_t)k * k + 2 * (size_t)k));
         WDX_HIP_TRY(hipFuncSetAttribute((const void *)svm_predict_mfma_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

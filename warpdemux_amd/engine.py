@@ -127,7 +127,9 @@ class DemuxEngine:
             raise ValueError("the SVM's training set must be the engine's reference set")
         self._svm_model = model   # keeps the host arrays alive during the upload
         m = model.to_c()
+        self.ctx._svm_owner = None
         _lib.check(self.L.wdx_svm_set_model(self.ctx.handle, C.byref(m)))
+        self.ctx._svm_owner = model
         self.n_classes = model.n_classes
 
     def svm_predict(self, dist):

@@ -50,7 +50,6 @@ class DTW_SVM:
         self.n_classes = int(self._n_support.size)
         self._label_arr = np.array([self.label_mapper[i] for i in range(self.n_classes)], dtype=np.int32)
         self._device = device
-        self._uploaded_ctx = None
 
     @classmethod
     def from_reference(cls, model, device: Optional[int] = None) -> "DTW_SVM":
@@ -84,15 +83,19 @@ class DTW_SVM:
         )
 
     def _ensure_resident(self):
+        """References and SVM parameters on the process's context.  The context holds ONE reference set and ONE
+        model at a time and other calls (distance_matrix_to, set_references, another DTW_SVM) may have replaced
+        either: the reference set is re-submitted on every call (the library compares a content hash and uploads
+        only on change), the model whenever this object is not the one the context last received."""
         ctx = _lib.default_context(self._device)
-        if self._uploaded_ctx is ctx:
-            return ctx
         L = _lib.load()
         _lib.check(L.wdx_set_refs(ctx.handle, _lib.ptr(self._X), self._X.shape[0], self._X.shape[1],
                                   int(self.window) if self.window else 0, float(self.penalty) if self.penalty else 0.0))
-        m = self.to_c()
-        _lib.check(L.wdx_svm_set_model(ctx.handle, C.byref(m)))
-        self._uploaded_ctx = ctx
+        if getattr(ctx, "_svm_owner", None) is not self:
+            ctx._svm_owner = None
+            m = self.to_c()
+            _lib.check(L.wdx_svm_set_model(ctx.handle, C.byref(m)))
+            ctx._svm_owner = self
         return ctx
 
     def predict(self, X: np.ndarray, nproc: int = -1, block_size: Optional[int] = None, pbar: bool = False,

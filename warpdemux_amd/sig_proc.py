@@ -188,9 +188,34 @@ def set_references(refs, window=None, penalty=None, device=None):
     if refs.ndim != 2:
         raise ValueError("refs must be (nY, L)")
     ctx = _lib.default_context(device)
-    _lib.check(_lib.load().wdx_set_refs(ctx.handle, _lib.ptr(refs), refs.shape[0], refs.shape[1],
-                                        int(window) if window else 0, float(penalty) if penalty else 0.0))
+    _submit_references(ctx, refs, window, penalty)
+    ctx._demux_refs = (refs, window, penalty)   # re-submitted by demux_batch if another call replaces them
     return refs.shape
+
+
+def _submit_references(ctx, refs, window, penalty):
+    import ctypes as C
+
+    L = _lib.load()
+    _lib.check(L.wdx_set_refs(ctx.handle, _lib.ptr(refs), refs.shape[0], refs.shape[1],
+                              int(window) if window else 0, float(penalty) if penalty else 0.0))
+    gen = C.c_int64(0)
+    _lib.check(L.wdx_refs_generation(ctx.handle, C.byref(gen)))
+    ctx._demux_refs_gen = gen.value
+
+
+def _ensure_references(ctx):
+    """The context holds one reference set; distance_matrix_to / a DTW_SVM model may have replaced the one
+    `set_references` installed.  One counter read per call tells (wdx_refs_generation)."""
+    import ctypes as C
+
+    held = getattr(ctx, "_demux_refs", None)
+    if held is None:
+        return
+    gen = C.c_int64(0)
+    _lib.check(_lib.load().wdx_refs_generation(ctx.handle, C.byref(gen)))
+    if gen.value != ctx._demux_refs_gen:
+        _submit_references(ctx, *held)
 
 
 def demux_batch(signals, adapter_start, adapter_end, params: SegParams, success=None, want_dist=True,
@@ -216,6 +241,7 @@ def demux_batch(signals, adapter_start, adapter_end, params: SegParams, success=
     call = np.empty(n, dtype=np.int32)
     status = np.empty(n, dtype=np.int32)
     ctx = _lib.default_context(device)
+    _ensure_references(ctx)
     _lib.check(_lib.load().wdx_demux_batch(
         ctx.handle, _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e), _lib.ptr(ok), C.byref(pc),
         _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call), _lib.ptr(status)))
