@@ -166,16 +166,16 @@ __global__ __launch_bounds__(256) void svm_predict_kernel(SvmDev M, const float 
 // scikit-learn at ~1e-7 relative anyway, tolerances in tests/.)
 typedef double wdx_d4 __attribute__((ext_vector_type(4)));
 
+template <bool PWR1>  // pwr_dist == 1 (every shipped model): no powf in the inner loop
 __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const float *__restrict__ dist,
                                                               int64_t n, double *__restrict__ prob,
                                                               int32_t *__restrict__ pred,
                                                               double *__restrict__ conf) {
-    extern __shared__ double svm_lds[];  // dec[16][npairs] | 4 x (pw[k*k] | Q[k*k] | p[k] | Qp[k])
+    extern __shared__ double svm_lds[];  // dec[16][npairs] | 4 x pw[k*k]
     const int k = M.k, npairs = k * (k - 1) / 2;
     const int lane = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * 16;
     double *dec = svm_lds;
-    const int grp_doubles = 2 * k * k + 2 * k;
     double *grp_base = dec + 16 * npairs;
 
     for (int idx = lane; idx < 16 * npairs; idx += 64) dec[idx] = -M.rho[idx % npairs];
@@ -191,16 +191,32 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
         for (int c = 0; c < k; ++c) {
             const int s0 = M.start[c], cn = M.n_support[c];
             wdx_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int t = 0; t < cn; t += 4) {
-                const int s = s0 + t + kk;
-                const bool ok = t + kk < cn;
-                const int sc = ok ? s : s0;
-                const float d = drow[M.support[sc]];
-                const float tt = M.pwr == 1 ? d : (M.pwr == 2 ? d * d : powf(d, (float)M.pwr));
-                const double a = ok ? (double)expf(M.ngamma * tt) : 0.0;
-                const double b = (ok && qrow) ? crow[sc] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            // 64 support vectors (16 matrix steps) at a time: their training-set indices by one coalesced
+            // load + lane shuffles, then all 16 distance loads and all 16 coefficient loads of the lane in
+            // flight together -- the loop is otherwise a chain of two dependent global loads per step
+            for (int cb = 0; cb < cn; cb += 64) {
+                const int rem = cn - cb;
+                const int sup = M.support[s0 + (lane < rem ? cb + lane : 0)];
+                float dv[16];
+                double bv[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int l = 4 * t + kk;
+                    const int sidx = __shfl(sup, l);
+                    dv[t] = drow[sidx];
+                    bv[t] = crow[s0 + (l < rem ? cb + l : 0)];
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if (4 * t < rem) {  // wave-uniform
+                        const bool ok = 4 * t + kk < rem;
+                        const float d = dv[t];
+                        const float tt = PWR1 ? d : (M.pwr == 2 ? d * d : powf(d, (float)M.pwr));
+                        const double a = ok ? (double)expf(M.ngamma * tt) : 0.0;
+                        const double b = (ok && qrow) ? bv[t] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    }
+                }
             }
             // acc[reg] = P[read kk + 4 reg][q = ar][c]  ->  its pair
             if (qrow) {
@@ -215,12 +231,14 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
-    // ---- phase 2: Platt sigmoids + libsvm's pairwise coupling, four reads at a time (16 lanes each)
-    const int g = lane >> 4, t = lane & 15;
-    double *pw = grp_base + g * grp_doubles;
-    double *Q = pw + k * k;
-    volatile double *pp = Q + k * k;
-    volatile double *Qp = pp + k;
+    // ---- phase 2: Platt sigmoids + libsvm's pairwise coupling, four reads at a time (16 lanes each).
+    // Lane t of a group owns row t of Q in REGISTERS (Q is symmetric, so Q[u][t] of the update step is
+    // its own element u) together with Qp[t] and p[t]; what the sweep needs from other lanes (Qp[u], p[j])
+    // comes by lane shuffle, the diagonal is replicated once per read.  No LDS round trip and no barrier
+    // inside the iteration: it is a chain of ~k shuffles + divisions per sweep, and with only the decision
+    // values and the pairwise table left in LDS more than twice as many waves fit a CU to hide it.
+    const int g = lane >> 4, t = lane & 15, gbase = lane & 48;
+    double *pw = grp_base + g * (k * k);
     const bool on = t < k;
     for (int rnd = 0; rnd < 4; ++rnd) {
         const int rl = rnd * 4 + g;  // read of this group within the tile
@@ -241,66 +259,81 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (on) {
+        double qrow[16];  // (the diagonal element of the sweep step comes by shuffle: registers are what limits the wave count)
+        {
             double qtt = 0.0;
-            for (int j = 0; j < k; ++j)
-                if (j != t) qtt += pw[j * k + t] * pw[j * k + t];
-            for (int j = 0; j < k; ++j) Q[t * k + j] = (j == t) ? qtt : -pw[j * k + t] * pw[t * k + j];
-            pp[t] = 1.0 / k;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool in = on && j < k && j != t;
+                const double a = in ? pw[j * k + t] : 0.0;  // r[j][t]
+                const double b = in ? pw[t * k + j] : 0.0;  // r[t][j]
+                qtt += a * a;
+                qrow[j] = -a * b;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) qrow[j] = (j == t) ? qtt : qrow[j];
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();  // pw is rewritten for the next read only after every lane has its row
+        double pt = 1.0 / k, qp = 0.0;
         const double eps = 0.005 / k;
         const int max_iter = k > 100 ? k : 100;
         bool live = true;  // per 16-lane group; the wave keeps sweeping until every group has converged
         for (int iter = 0; iter < max_iter; ++iter) {
-            double qp = 0.0;
-            if (on)
-                for (int j = 0; j < k; ++j) qp += Q[t * k + j] * pp[j];
-            if (on && live) Qp[t] = qp;
-            __builtin_amdgcn_wave_barrier();
+            // Qp[t] = sum_j Q[t][j] p[j] and pQp = sum_t p[t] Qp[t], both in libsvm's index order
+            double qn = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < k) qn += qrow[j] * __shfl(pt, gbase + j);
+            if (live) qp = qn;
+            const double pq = pt * qp;
             double pQp = 0.0;
-            for (int j = 0; j < k; ++j) pQp += pp[j] * Qp[j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < k) pQp += __shfl(pq, gbase + j);
             double err = on ? fabs(qp - pQp) : 0.0;
             for (int off = 8; off > 0; off >>= 1) err = fmax(err, __shfl_xor(err, off));
             if (err < eps) live = false;
             if (!__ballot(live)) break;
-            for (int u = 0; u < k; ++u) {
-                const double Quu = Q[u * k + u];
-                const double diff = (-Qp[u] + pQp) / Quu;
-                __builtin_amdgcn_wave_barrier();
-                double pt = 0.0, qpn = 0.0;
-                if (on) {
-                    pt = pp[t];
-                    if (t == u) pt += diff;
-                    qpn = (Qp[t] + diff * Q[u * k + t]) / (1 + diff);
-                    pt /= (1 + diff);
-                }
-                pQp = (pQp + diff * (diff * Quu + 2 * Qp[u])) / (1 + diff) / (1 + diff);
-                __builtin_amdgcn_wave_barrier();
-                if (on && live) {
-                    Qp[t] = qpn;
-                    pp[t] = pt;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (r < n) {
-            if (on && prob) prob[r * k + t] = pp[t];
-            if (t == 0) {
-                int best = 0;
-                double b1 = pp[0], b2 = -1.0;
-                for (int j = 1; j < k; ++j) {
-                    const double v = pp[j];
-                    if (v > b1) {
-                        b2 = b1;
-                        b1 = v;
-                        best = j;
-                    } else if (v > b2) {
-                        b2 = v;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (u < k) {  // wave-uniform
+                    // libsvm divides three times by (1 + diff); one reciprocal here, which moves the iterates
+                    // by ~1e-16
+                    const double Qpu = __shfl(qp, gbase + u);
+                    const double Quu = __shfl(qrow[u], gbase + u);
+                    const double diff = (-Qpu + pQp) / Quu;
+                    const double inv = 1.0 / (1 + diff);
+                    double pn = pt;
+                    if (t == u) pn += diff;
+                    pn *= inv;
+                    const double qpn = (qp + diff * qrow[u]) * inv;
+                    pQp = (pQp + diff * (diff * Quu + 2 * Qpu)) * inv * inv;
+                    if (live) {
+                        pt = pn;
+                        qp = qpn;
                     }
                 }
+            }
+        }
+        // process_probs: np.argmax (first maximum), margin top1 - top2, per-class threshold
+        int best = 0;
+        double b1 = __shfl(pt, gbase), b2 = -1.0;
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            if (j < k) {
+                const double v = __shfl(pt, gbase + j);
+                if (v > b1) {
+                    b2 = b1;
+                    b1 = v;
+                    best = j;
+                } else if (v > b2) {
+                    b2 = v;
+                }
+            }
+        }
+        if (r < n) {
+            if (on && prob) prob[r * k + t] = pt;
+            if (t == 0) {
                 const double margin = b1 - b2;
                 int label = M.label_map ? M.label_map[best] : best;
                 if (M.thresholds && margin < M.thresholds[best]) label = -1;
@@ -308,7 +341,6 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
                 if (conf) conf[r] = margin;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -317,15 +349,16 @@ int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *
     if (n == 0) return WDX_SUCCESS;
     const int k = M.k;
     if (k >= 2 && k <= 16 && !getenv("WDX_SVM_NO_MFMA")) {
-        const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (2 * (size_t)k * k + 2 * (size_t)k));
-        WDX_HIP_TRY(hipFuncSetAttribute((const void *)svm_predict_mfma_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (size_t)k * k);
+        void (*kern)(SvmDev, const float *, int64_t, double *, int32_t *, double *) =
+            M.pwr == 1 ? svm_predict_mfma_kernel<true> : svm_predict_mfma_kernel<false>;
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         const int64_t tiles = (n + 15) / 16;
         const int64_t slice = (1ll << 31) / 64;
         for (int64_t base = 0; base < tiles; base += slice) {
             const int64_t m = tiles - base < slice ? tiles - base : slice;
             const int64_t rb = base * 16, rn = n - rb < m * 16 ? n - rb : m * 16;
-            hipLaunchKernelGGL(svm_predict_mfma_kernel, dim3((unsigned)m), dim3(64), lds2, stream, M,
+            hipLaunchKernelGGL(kern, dim3((unsigned)m), dim3(64), lds2, stream, M,
                                d_dist + rb * M.n_train, rn, d_prob ? d_prob + rb * k : nullptr,
                                d_pred ? d_pred + rb : nullptr, d_conf ? d_conf + rb : nullptr);
         }
