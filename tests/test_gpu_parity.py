@@ -661,7 +661,7 @@ def _styled_signal(rng, ln, style):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WDX_SOAK_SEEDS", "16"))))   # soak: WDX_SOAK_SEEDS=400
 def test_fingerprint_randomised_configs_and_signal_styles(seed):
     """Random segmentation parameters x signal styles (quantised, integer-valued, heavy-tailed, negative,
     spiky, flat runs, low-clipped) x window lengths on both sides of every fast-path capacity: GPU == oracle,
