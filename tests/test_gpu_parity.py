@@ -694,3 +694,30 @@ def test_fingerprint_randomised_configs_and_signal_styles(seed):
     _RANDOMISED_OK.append(int((status == 0).sum()))
     if seed == 15:
         assert sum(_RANDOMISED_OK) > 4 * n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WDX_SOAK_SEEDS", "24"))))
+def test_dtw_randomised_shapes_windows_penalties(seed):
+    """Random series lengths, windows, penalties and batch shapes: every DTW kernel the dispatcher can pick
+    (rolling band 8/15/16/32, unrolled 25x15, wavefront rows for few pairs, scratch rows for wide windows,
+    fused argmin or separate) against the oracle, float32 distances bit for bit."""
+    rng = np.random.default_rng(5000 + seed)
+    L = int(rng.choice([1, 2, 7, 16, 24, 25, 26, 28, 29, 40, 64, 110, 111, 150]))
+    w = rng.choice([None, 0, 1, 2, 3, 8, 9, 15, 16, 17, 31, 32, 33, 40, L, L + 3])
+    w = None if w is None else int(w)
+    p = rng.choice([None, 0.0, 0.1, 0.75, 1.5])
+    p = None if p is None else float(p)
+    nX = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 2500]))
+    nY = int(rng.choice([1, 2, 4, 10, 33, 200, 851]))
+    if nX * nY * L > 4e7:
+        nX = 300
+    X, Y = rng.normal(size=(nX, L)), rng.normal(size=(nY, L))
+    if rng.uniform() < 0.2 and nX > 2:
+        X[1, rng.integers(0, L)] = np.nan
+    ref = orc.dtw_matrix(X, Y, w, p)
+    got, am = pdist.nearest_reference(X, Y, w, p)
+    _check_dist(got, ref)
+    ok_rows = ~np.isnan(ref).any(axis=1)
+    assert np.array_equal(am[ok_rows], np.argmin(ref[ok_rows], axis=1))
+    _check_dist(pdist.distance_matrix_to(X, Y, window=w, penalty=p, n_jobs=1), ref)
