@@ -466,13 +466,17 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
         return WDX_ERR_INVALID;
     }
     // exact bound on the adapter window over this batch (extract_adapter, sig_proc.py:388-389)
-    int64_t max_len = 0;
+    int64_t max_len = 0, col0 = stride, col1 = 0;  // columns [col0, col1) hold every adapter window of the batch
     for (int64_t r = 0; r < n_reads; ++r) {
         if (ok && !ok[r]) continue;
         int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
         if (st < 0) st = 0;
         if (en > stride) en = stride;
         if (en - st > max_len) max_len = en - st;
+        if (en > st) {
+            if (st < col0) col0 = st;
+            if (en > col1) col1 = en;
+        }
     }
     const size_t sb = (size_t)(n_reads * stride) * sizeof(float);
     if ((rc = ctx->in0.ensure(sb ? sb : 4))) return rc;
@@ -484,7 +488,12 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
     if ((rc = ctx->out2.ensure((size_t)n_reads * 6 * 8))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
-    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, sig, sb, hipMemcpyHostToDevice, s));
+    // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
+    // file_proc.py:244-260; the kernels never read outside [start, stop))
+    if (col1 > col0)
+        WDX_HIP_TRY(hipMemcpy2DAsync((float *)ctx->in0.p + col0, (size_t)stride * sizeof(float), sig + col0,
+                                     (size_t)stride * sizeof(float), (size_t)(col1 - col0) * sizeof(float),
+                                     (size_t)n_reads, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     if (ok) WDX_HIP_TRY(hipMemcpyAsync(ctx->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
@@ -594,13 +603,17 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
         return WDX_ERR_INVALID;
     }
     hipStream_t s = nullptr;
-    int64_t max_len = 0;
+    int64_t max_len = 0, col0 = stride, col1 = 0;  // columns [col0, col1) hold every adapter window of the batch
     for (int64_t r = 0; r < n_reads; ++r) {
         if (ok && !ok[r]) continue;
         int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
         if (st < 0) st = 0;
         if (en > stride) en = stride;
         if (en - st > max_len) max_len = en - st;
+        if (en > st) {
+            if (st < col0) col0 = st;
+            if (en > col1) col1 = en;
+        }
     }
     const size_t sb = (size_t)(n_reads * stride) * sizeof(float);
     const size_t db = (size_t)(n_reads * (R.nY > 0 ? R.nY : 1)) * sizeof(float);
@@ -613,7 +626,12 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     if ((rc = ctx->out2.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
-    WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, sig, sb, hipMemcpyHostToDevice, s));
+    // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
+    // file_proc.py:244-260; the kernels never read outside [start, stop))
+    if (col1 > col0)
+        WDX_HIP_TRY(hipMemcpy2DAsync((float *)ctx->in0.p + col0, (size_t)stride * sizeof(float), sig + col0,
+                                     (size_t)stride * sizeof(float), (size_t)(col1 - col0) * sizeof(float),
+                                     (size_t)n_reads, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     if (ok) WDX_HIP_TRY(hipMemcpyAsync(ctx->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
