@@ -244,7 +244,7 @@ def main():
 
     valu_busy = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01h_sq_counters.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01i_sq_counters.json")) as fh:
             pl = json.load(fh)["kernels"][dom.split("<")[0]]["per_launch"]
         valu_busy = pl["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pl["GRBM_GUI_ACTIVE"] / 8.0)
     except (OSError, ValueError, KeyError):
