@@ -2,25 +2,35 @@
 """Headline benchmark: reads/s demultiplexed on synthetic RNA004 adapter signals.
 
 One "step" = one pass of the fused hot path (fingerprint -> banded DTW against the barcode
-references -> call -> count histogram [-> all-reduce]) over the rank's whole batch of raw adapter
+references -> call -> count histogram -> count all-reduce) over the rank's whole shard of raw adapter
 rows, which is resident in HBM when the timed region starts (generated on the device by the
-"wdx-synth v1" kernels).  Workload at N=1: BASELINE.json configs[2] (C3) -- 10 M reads, WDX10
-shape (10 barcodes x 110-point fingerprints, window 15, penalty 0.1).  For N>1 every rank holds
-its own shard of the same size (weak scaling, no data-path collective; one int64[11] all-reduce
-of the call histogram per step).
+"wdx-synth v1" kernels).
+
+* N=1: BASELINE.json configs[2] (C3) -- 10 M reads, WDX10 shape (10 barcodes x 110-point
+  fingerprints, window 15, penalty 0.1).
+* N>1: BASELINE.json configs[3] (C4) -- 5 M reads per GPU (40 M at N=8), contiguous shards of one
+  global read range (`dist.shard_range`), no data-path collective, ONE int64[11] all-reduce of the
+  call histogram per step through the C ABI's RCCL communicator (`wdx_reduce_counts`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With `--gpus N` (N>1) and no torchrun environment this process starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py`) BEFORE anything touches the GPU
+and forwards the ranks' output; under torchrun it is one rank.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
-HIP-event timed on the launch stream) and `cpu_baseline` (the CPU oracle -- a port of the
-reference's CPU path -- timed on this host on a bounded sample of the same reads).
+HIP-event timed on the launch stream), `cpu_baseline` (the CPU oracle -- a port of the reference's
+CPU path -- timed on this host on a bounded sample of the same reads, which doubles as the parity
+gate) and, at N=1, `secondary` (the shipped-model DTW regime, host-buffer minibatches, live ticks
+and DTW_SVM.predict, each with its own parity check).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,72 +38,346 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 N_BARCODES = 10
 K_FPT = 110
 WINDOW = 15
 PENALTY = 0.1
+CELLS_110 = sum(min(110, i + 15) - max(0, i - 14) for i in range(110))  # 2 980 per pair
+CELLS_25 = sum(min(25, i + 15) - max(0, i - 14) for i in range(25))     # 515 per pair
 
 
-def _cpu_minibatch(args):
-    """Worker of the CPU baseline: one 1000-read minibatch, driven like file_proc.py:418-450."""
-    sig, off, a_s, a_e, refs = args
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: C3 = 10 M at N=1, C4 = 5 M at N>1)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0,
+                    help="time budget of the CPU baseline / parity gate (oracle on all host cores)")
+    ap.add_argument("--parity-reads", type=int, default=1_000_000,
+                    help="upper bound of reads verified against the oracle inside the time budget; a run with "
+                         "--cpu-seconds 0 verifies exactly this many")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--calib", action="store_true", help="also stream the signal buffer once with the calibration "
+                    "kernel (known byte count for the FETCH_SIZE counter; tools/collect_traffic.py)")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own ranks (children first, no GPU call in this process)
+# ----------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------
+# CPU baseline = the oracle (a port of the reference's CPU path) on the host cores, and the parity gate
+# ----------------------------------------------------------------------------------------------------
+def _oracle_minibatch(job):
+    """One <=1000-read minibatch driven like file_proc.py:418-450: per-read fingerprints, then one
+    distance_matrix_to(n_jobs=1) call and the nearest-reference call.  Runs in a worker THREAD (ctypes
+    drops the GIL inside the C oracle), so inputs are views -- no pickling, no fork."""
+    import numpy as np
+
     from oracle import wdx_oracle as orc
 
-    p = orc.SegParams(barcode_num_events=K_FPT)
+    sig, off, a_s, a_e, refs, K = job
+    p = orc.SegParams(barcode_num_events=K)
     fpt, dwell, stats, status = orc.fingerprint_packed(sig, off, a_s, a_e, p)
     ok = status == 0
-    D = orc.dtw_matrix(fpt[ok], refs, WINDOW, PENALTY)
+    D = np.full((status.size, refs.shape[0]), np.nan, dtype=np.float32)
+    D[ok] = orc.dtw_matrix(fpt[ok], refs, WINDOW, PENALTY)
     call = np.full(status.size, -1, dtype=np.int32)
-    call[ok] = orc.argmin_rows(D)
-    return call, status, D
+    call[ok] = orc.argmin_rows(D[ok])
+    return call, status, D, fpt, dwell
 
 
-def cpu_baseline(sig_h, off_h, a_s_h, a_e_h, refs, gpu_call, gpu_status, gpu_dist):
-    """Oracle (kind="port") on all host cores, minibatches farmed to a process pool like
-    file_proc.run_demux, + a 1-core figure; also returns whether the GPU results on the same sample
-    are identical."""
-    from concurrent.futures import ProcessPoolExecutor
+def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_s, max_reads):
+    """Walks the first reads of the workload in 32 768-read chunks until the time budget or `max_reads`
+    is reached: oracle on all host cores (timed), GPU results of the same reads compared bit for bit --
+    status, call, float32 distances, float64 fingerprints and the int64 dwell times (= the change-points).
+    Returns the cpu_baseline object and the parity record."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
 
-    n = off_h.size - 1
     cores = os.cpu_count() or 1
-    mb = max(100, min(1000, -(-n // cores)))  # reference minibatch is 1000 reads; shrink to occupy every core
-    jobs = []
-    for lo in range(0, n, mb):
-        hi = min(n, lo + mb)
-        o = off_h[lo:hi + 1]
-        jobs.append((sig_h[o[0]:o[-1]], (o - o[0]).copy(), a_s_h[lo:hi], a_e_h[lo:hi], refs))
-    # 1 core: a few minibatches in this process
-    n1 = max(1, min(len(jobs), 2000 // mb))
-    t0 = time.perf_counter()
-    one = [_cpu_minibatch(j) for j in jobs[:n1]]
-    t1 = time.perf_counter()
-    single = sum(j[2].size for j in jobs[:n1]) / (t1 - t0)
-    del one
-    with ProcessPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(_cpu_noop, range(cores * 2)))  # start the workers before the clock
+    chunk = 32768
+    mb = 1000 if cores * 1000 <= chunk else max(64, chunk // cores)
+    t_cpu = 0.0
+    n_done = 0
+    single = None
+    bad = {"status": 0, "call": 0, "dist": 0, "fpt": 0, "dwell": 0}
+    max_rel = 0.0
+    t_start = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(lambda i: i, range(cores)))  # threads exist before the clock starts
+        while n_done < min(max_reads, n_reads):
+            if budget_s > 0 and n_done > 0 and (time.perf_counter() - t_start) > budget_s:
+                break
+            lo, hi = n_done, min(n_done + chunk, n_reads, max_reads)
+            o = off[lo:hi + 1].cpu().numpy()
+            sig_h = sig[int(o[0]):int(o[-1])].cpu().numpy()
+            as_h, ae_h = a_s[lo:hi].cpu().numpy(), a_e[lo:hi].cpu().numpy()
+            # GPU side of the gate: fingerprint + dwell of the same reads (the fused call keeps neither)
+            g_fpt, g_dwell, _, g_status = eng.fingerprint(sig[int(o[0]):int(o[-1])], a_s[lo:hi], a_e[lo:hi],
+                                                          offsets=off[lo:hi + 1] - off[lo], max_len=int((o[1:] - o[:-1]).max()))
+            g_fpt, g_dwell, g_status = g_fpt.cpu().numpy(), g_dwell.cpu().numpy(), g_status.cpu().numpy()
+            jobs = []
+            for a in range(0, hi - lo, mb):
+                b = min(hi - lo, a + mb)
+                oo = o[a:b + 1]
+                jobs.append((sig_h[oo[0] - o[0]:oo[-1] - o[0]], oo - oo[0], as_h[a:b], ae_h[a:b], refs, K_FPT))
+            if single is None:  # 1-core figure: one minibatch in this thread
+                t0 = time.perf_counter()
+                _oracle_minibatch(jobs[0])
+                single = (jobs[0][1].size - 1) / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            out = list(ex.map(_oracle_minibatch, jobs))
+            t_cpu += time.perf_counter() - t0
+            call = np.concatenate([r[0] for r in out])
+            status = np.concatenate([r[1] for r in out])
+            D = np.concatenate([r[2] for r in out])
+            fpt = np.concatenate([r[3] for r in out])
+            dwell = np.concatenate([r[4] for r in out])
+            okm = status == 0
+            g_call = res.call[lo:hi].cpu().numpy()
+            g_dist = res.dist[lo:hi].cpu().numpy()
+            g_st = res.status[lo:hi].cpu().numpy()
+            bad["status"] += int((status != g_st).sum() + (status != g_status).sum())
+            bad["call"] += int((call != g_call).sum())
+            bad["dist"] += int((D[okm].view(np.uint32) != g_dist[okm].view(np.uint32)).any(axis=1).sum())
+            bad["fpt"] += int((fpt[okm].view(np.uint64) != g_fpt[okm].view(np.uint64)).any(axis=1).sum())
+            bad["dwell"] += int((dwell[okm] != g_dwell[okm]).any(axis=1).sum())
+            with np.errstate(invalid="ignore", divide="ignore"):
+                rel = np.abs(D[okm].astype(np.float64) - g_dist[okm]) / np.abs(D[okm].astype(np.float64))
+            if rel.size:
+                max_rel = max(max_rel, float(np.nanmax(rel)))
+            n_done = hi
+    parity_ok = not any(bad.values())
+    cpu = {
+        "value": n_done / t_cpu if t_cpu > 0 else None,
+        "unit": "reads/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": ("first %d reads of the same workload; oracle/wdx_oracle.c (C restatement of sig_proc.py:394-605 + "
+                   "dtaidistance's banded DTW) driven as %d-read minibatches like file_proc.py:418-450, one worker thread "
+                   "per host core on shared buffers (no IPC); dtaidistance itself: see `dtaidistance`" % (n_done, mb)),
+        "single_core_value": single,
+        "parallel_efficiency": (n_done / t_cpu) / (single * cores) if (single and t_cpu > 0) else None,
+        "cpu_seconds": t_cpu,
+    }
+    parity = {
+        "reads_checked": n_done,
+        "checked": "status, call (argmin), float32 distances, float64 fingerprints, int64 dwell (change-points): bitwise",
+        "mismatching_reads": bad,
+        "max_rel_dist_err": max_rel,
+        "ok": parity_ok,
+    }
+    return cpu, parity
+
+
+def try_dtaidistance(eng, refs, res_fpt_sample):
+    """if the genuine reference library is importable on this box, compare it with the HIP
+    matrix on >= 1e4 pairs (R1 and R2 shapes) and time it; otherwise record null (never an error)."""
+    import numpy as np
+
+    try:
+        import dtaidistance
+        from dtaidistance import dtw
+    except Exception:  # noqa: BLE001
+        return None
+    import torch
+
+    from warpdemux_amd import parallel_distances as pdist
+
+    out = {"version": getattr(dtaidistance, "__version__", "?")}
+    rng = np.random.default_rng(7)
+    for name, X, Y in (("r1", res_fpt_sample[:1000], refs), ("r2", rng.normal(size=(64, 25)), rng.normal(size=(851, 25)))):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        stack = np.vstack([X, Y])
+        nX = X.shape[0]
         t0 = time.perf_counter()
-        res = list(ex.map(_cpu_minibatch, jobs))
+        ref = dtw.distance_matrix(stack, block=((0, nX), (nX, nX + Y.shape[0])), parallel=False, use_c=True,
+                                  only_triu=True, window=WINDOW, penalty=PENALTY)[:nX, nX:].astype(np.float32)
+        dt = time.perf_counter() - t0
+        mine = pdist.distance_matrix_to(X, Y, window=WINDOW, penalty=PENALTY, n_jobs=1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = float(np.nanmax(np.abs(mine.astype(np.float64) - ref) / np.abs(ref)))
+        out[name] = {"pairs": int(mine.size), "bit_identical": bool(np.array_equal(mine, ref)), "max_rel": rel,
+                     "argmin_identical": bool(np.array_equal(mine.argmin(1), ref.argmin(1))),
+                     "reference_pairs_per_s_1core": mine.size / dt}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# secondary regimes (N=1 only): driver-timed, each with a parity check on its own sample
+# ----------------------------------------------------------------------------------------------------
+def _oracle_dtw_threads(X, Y, budget_s=3.0, rows_per_job=32):
+    """oracle DTW of as many leading rows of X as fit the time budget, on all cores -> (D, rows)"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import wdx_oracle as orc
+
+    cores = os.cpu_count() or 1
+    outs, done, t0 = [], 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        while done < X.shape[0] and (done == 0 or time.perf_counter() - t0 < budget_s):
+            hi = min(X.shape[0], done + rows_per_job * cores)
+            parts = [X[a:min(hi, a + rows_per_job)] for a in range(done, hi, rows_per_job)]
+            outs += list(ex.map(lambda x: orc.dtw_matrix(x, Y, WINDOW, PENALTY), parts))
+            done = hi
+    return np.concatenate(outs), done
+
+
+def secondary_regimes(device):
+    import numpy as np
+    import torch
+
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import _lib
+    from warpdemux_amd import parallel_distances as pdist
+    from warpdemux_amd import sig_proc, synth
+    from warpdemux_amd.engine import DemuxEngine
+    from warpdemux_amd.live import LiveDemux
+    from warpdemux_amd.models import DTW_SVM
+
+    out = {}
+    rng = np.random.default_rng(0)
+    tdev = torch.device("cuda", device)
+
+    def sync():
+        torch.cuda.synchronize(tdev)
+
+    # ---- r2: shipped-model DTW shape (L=25, window 15), nY = 2601 (WDX10's training set size) ----------
+    nY, nX = 2601, 100_000
+    Y = rng.normal(size=(nY, 25))
+    eng = DemuxEngine(Y, WINDOW, PENALTY, sig_proc.SegParams(barcode_num_events=25), device=device)
+    Xh = rng.normal(size=(nX, 25))
+    X = torch.from_numpy(Xh).to(tdev)
+    d, am = eng.dtw(X)
+    sync()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        d, am = eng.dtw(X)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    Dref, rows = _oracle_dtw_threads(Xh, Y, budget_s=3.0)
+    dh = d[:rows].cpu().numpy()
+    out["r2"] = {"workload": "device-resident DTW, 100 000 reads x 2601 refs x 25 points (window 15, penalty 0.1)",
+                 "reads_per_s": nX / dt, "gcups": nX * nY * CELLS_25 / dt / 1e9, "ms": dt * 1e3,
+                 "parity": bool(np.array_equal(dh.view(np.uint32), Dref.view(np.uint32))
+                                and np.array_equal(am[:rows].cpu().numpy(), orc.argmin_rows(Dref))),
+                 "parity_pairs": int(rows * nY)}
+    del X, d, am
+    eng.close()
+
+    # ---- host_minibatch: what file_proc.py:418-450 would pass -- 1000 x 10 000 float32 rows, PCIe included -----
+    spec = synth.SynthSpec(n_barcodes=N_BARCODES)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 0, 1000, 10000)
+    p110 = sig_proc.SegParams(barcode_num_events=K_FPT)
+    Y10 = rng.normal(size=(N_BARCODES, K_FPT))
+    for _ in range(2):
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, p110, device=device)
+        Dm = pdist.distance_matrix_to(fb.fpt[fb.status == 0], Y10, window=WINDOW, penalty=PENALTY, n_jobs=1)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, p110, device=device)
         t1 = time.perf_counter()
-    multi = n / (t1 - t0)
-    call = np.concatenate([r[0] for r in res])
-    status = np.concatenate([r[1] for r in res])
-    D = np.concatenate([r[2] for r in res])
-    ok = status == 0
-    parity = bool(np.array_equal(call, gpu_call) and np.array_equal(status, gpu_status)
-                  and np.array_equal(D, gpu_dist[ok]))
-    return multi, cores, single, parity, mb
+        Dm = pdist.distance_matrix_to(fb.fpt[fb.status == 0], Y10, window=WINDOW, penalty=PENALTY, n_jobs=1)
+    dt = (time.perf_counter() - t0) / reps
+    ofpt, odw, ost, ostatus = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=K_FPT))
+    ook = ostatus == 0
+    oD = orc.dtw_matrix(ofpt[ook], Y10, WINDOW, PENALTY)
+    out["host_minibatch"] = {
+        "workload": "fingerprint_batch + distance_matrix_to on one 1000 x 10 000 float32 minibatch (host buffers, PCIe included), 110-pt x 10 refs",
+        "reads_per_s": 1000 / dt, "ms": dt * 1e3,
+        "parity": bool(np.array_equal(fb.status, ostatus) and np.array_equal(fb.fpt[ook], ofpt[ook])
+                       and np.array_equal(fb.dwell[ook], odw[ook]) and np.array_equal(Dm.view(np.uint32), oD.view(np.uint32)))}
+
+    # ---- live (C5): ticks of 1 / 64 / 512 reads through the live shim, WDX6 shape and the shipped WDX6 shape ------
+    live = {}
+    for K, nYl in ((K_FPT, 6), (25, 1368)):
+        pl = sig_proc.SegParams(barcode_num_events=K)
+        Yl = rng.normal(size=(nYl, K))
+        ld = LiveDemux(Yl, WINDOW, PENALTY, pl, device=device, max_reads=512, max_samples=10000)
+        oft, _, _, ost = orc.fingerprint_batch(mb[:512], a_s[:512], a_e[:512], orc.SegParams(barcode_num_events=K))
+        okl = ost == 0
+        oDl = orc.dtw_matrix(oft[okl], Yl, WINDOW, PENALTY)
+        for n, ticks in ((1, 2000), (64, 2000), (512, 2000)):
+            rows = [mb[i] for i in range(n)]
+            for _ in range(20):
+                r = ld.tick(rows, a_s[:n], a_e[:n])
+            lat = np.empty(ticks)
+            for i in range(ticks):
+                t0 = time.perf_counter()
+                r = ld.tick(rows, a_s[:n], a_e[:n])
+                lat[i] = time.perf_counter() - t0
+            lat *= 1e3
+            okn = ost[:n] == 0
+            par = bool(np.array_equal(r.status, ost[:n]) and
+                       np.array_equal(r.dist[okn].view(np.uint32), oDl[:int(okl[:n].sum())].view(np.uint32)) and
+                       np.array_equal(r.call[okn], orc.argmin_rows(oDl[:int(okl[:n].sum())])))
+            live[f"nY{nYl}_K{K}_reads{n}"] = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                                              "ticks": ticks, "reads_per_s": n / float(np.median(lat)) * 1e3, "parity": par}
+        ld.close()
+    out["live"] = {"workload": "LiveDemux.tick: all reads of one 100 ms chunk round -> fingerprint + DTW + nearest reference, "
+                               "host buffers in/out through pinned staging on the context's stream (reference: 4.3 ms + 13.5 ms per read)",
+                   **live}
+
+    # ---- dtw_svm_predict: WDX4-shaped DTW_SVM (851 x 25-pt training rows, 5 classes) on host fingerprints -------
+    try:
+        from sklearn.svm import SVC
+
+        k, n_train, L = 5, 851, 25
+        centers = rng.normal(size=(k, L))
+        y = rng.integers(0, k, n_train)
+        Xtr = centers[y] + 0.9 * rng.normal(size=(n_train, L))
+        Ktr = np.exp(-_oracle_dtw_threads(Xtr, Xtr, budget_s=1e9)[0].astype(np.float64))
+        svc = SVC(kernel="precomputed", probability=True, random_state=0).fit(Ktr, y)
+        sp = orc.svm_params(svc)
+        model = DTW_SVM(Xtr, *sp[:6], {i: i for i in range(k)}, None, WINDOW, PENALTY, block_size=1000, device=device)
+        nq = 200_000
+        yq = rng.integers(0, k, nq)
+        Xq = centers[yq] + 0.9 * rng.normal(size=(nq, L))
+        model.predict(Xq[:1000], nproc=1)
+        t0 = time.perf_counter()
+        y_pred, y_prob = model.predict(Xq, nproc=1)
+        dt = time.perf_counter() - t0
+        ns = 512
+        Kq = np.exp(-orc.dtw_matrix(Xq[:ns], Xtr, WINDOW, PENALTY))  # float32 exp like the reference (dtw_svm.py:21-22)
+        pref = svc.predict_proba(Kq)
+        out["dtw_svm_predict"] = {
+            "workload": "DTW_SVM.predict on 200 000 host fingerprints, WDX4-shaped model (851 x 25-pt rows, 5 classes), PCIe included",
+            "reads_per_s": nq / dt, "ms": dt * 1e3,
+            "parity": bool(np.abs(y_prob[:ns] - pref).max() <= 1e-5), "max_abs_prob_err": float(np.abs(y_prob[:ns] - pref).max()),
+            "parity_tolerance": 1e-5}
+    except ImportError:
+        out["dtw_svm_predict"] = None
+    return out
 
 
-def _cpu_noop(i):
-    return i
-
-
-def make_refs(spec_clean, synth, sig_proc):
+def make_refs(spec_clean, synth, sig_proc, device=None):
     """Barcode reference fingerprints: one low-noise template read per barcode through the HIP
     fingerprint kernel (host-buffer entry point)."""
+    import numpy as np
+
+    from warpdemux_amd import _lib
+
     ids, rid = {}, 0
     while len(ids) < N_BARCODES:
         b = int(synth.read_layout(spec_clean, np.array([rid]))[0][0])
@@ -108,28 +392,19 @@ def make_refs(spec_clean, synth, sig_proc):
     a_e = np.array([r.size - synth.PAD for r in rows], dtype=np.int32)
     # the 10 template reads go through the exact one-kernel path so that every launch of the fast kernel
     # seen by a profiler belongs to the timed workload (same results either way)
-    os.environ["WDX_FORCE_SLOW"] = "1"
+    ctx = _lib.default_context(device)
+    ctx.set_option(_lib.OPT_EXACT_PATH, 1)
     try:
-        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=K_FPT))
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=K_FPT), device=device)
     finally:
-        del os.environ["WDX_FORCE_SLOW"]
+        ctx.set_option(_lib.OPT_EXACT_PATH, 0)
     if not (fb.status == 0).all():
         raise RuntimeError("template fingerprinting failed")
     return fb.fpt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C3 = 10 M)")
-    ap.add_argument("--cpu-sample", type=int, default=64000, help="reads timed on the CPU oracle")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--calib", action="store_true", help="also stream the signal buffer once with the calibration "
-                    "kernel (known byte count for the FETCH_SIZE counter; tools/collect_traffic.py)")
-    args = ap.parse_args()
-
+def run_rank(args):
+    import numpy as np
     import torch
 
     from warpdemux_amd import _lib, dist, sig_proc, synth
@@ -143,37 +418,48 @@ def main():
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % n_dev)
     rank, local_rank, world = dist.init_process_group(backend)
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     tdev = torch.device("cuda", local_rank)
     host_collectives = backend == "gloo"
 
     spec = synth.SynthSpec(n_barcodes=N_BARCODES)
     clean = synth.SynthSpec(n_barcodes=N_BARCODES, noise_sigma=0.25, spikes=False)
-    os.environ["WDX_DEVICE"] = str(local_rank)
-    refs = make_refs(clean, synth, sig_proc)
+    refs = make_refs(clean, synth, sig_proc, local_rank)
     params = sig_proc.SegParams(barcode_num_events=K_FPT)
     eng = DemuxEngine(refs, WINDOW, PENALTY, params, device=local_rank)
+    reducer = dist.CountReducer(eng.ctx, prefer="torch" if host_collectives else None)
 
-    # ---- inputs: generated straight into HBM; shrink if the device cannot hold the batch --------
-    n_reads = args.reads
+    # ---- the global read range and this rank's contiguous shard of it ----------------------------
+    per_gpu = args.reads or (10_000_000 if world == 1 else 5_000_000)
+    workload = "C3" if world == 1 else "C4"
     while True:
+        total = per_gpu * world
+        lo, hi = dist.shard_range(total, rank, world)
+        n_reads = hi - lo
+        fit = 1
         try:
-            first = rank * n_reads
-            sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, first, n_reads)
+            sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, lo, n_reads)
             res = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len)  # allocates outputs/workspace
             torch.cuda.synchronize()
-            break
-        except (torch.OutOfMemoryError, RuntimeError, _lib.WdxError) as e:  # noqa: PERF203
-            if n_reads <= 100_000:
+        except torch.OutOfMemoryError:
+            fit = 0
+        except _lib.WdxError as e:
+            if "hipMalloc" not in str(e):
                 raise
-            sig = off = a_s = a_e = bc = res = None
-            eng._work = None
-            torch.cuda.empty_cache()
-            if rank == 0:
-                print(f"note: {n_reads} reads did not fit ({type(e).__name__}); halving", file=sys.stderr)
-            n_reads //= 2
+            fit = 0
+        # every rank takes the same decision (shards must tile the global range)
+        fit = int(dist.min_over_ranks(fit, device=None if host_collectives else tdev))
+        if fit:
+            break
+        if per_gpu <= 100_000:
+            raise RuntimeError("the device cannot hold even 100 000 reads")
+        sig = off = a_s = a_e = bc = res = None
+        eng._work = None
+        torch.cuda.empty_cache()
+        if rank == 0:
+            print(f"note: {per_gpu} reads per GPU did not fit; halving", file=sys.stderr)
+        per_gpu //= 2
     total_samples = int(off[-1].item())
 
     def step():
@@ -181,10 +467,10 @@ def main():
         eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, out=res)
         if host_collectives:
             c = res.counts.cpu()
-            dist.reduce_counts(c)
+            reducer(c)
             res.counts.copy_(c)
         else:
-            dist.reduce_counts(res.counts)
+            reducer(res.counts, stream=eng._stream())
 
     if args.calib:
         import ctypes as C
@@ -212,24 +498,26 @@ def main():
     dtw_ms, dtw_n = eng.kernel_time(_lib.K_DTW)
     tr_ms, tr_n = eng.kernel_time(_lib.K_TRANSPOSE)
     cnt_ms, cnt_n = eng.kernel_time(_lib.K_COUNT)
+    red_ms, red_n = eng.kernel_time(_lib.K_REDUCE)
 
     counts = res.counts.cpu().numpy()
     n_fail = int(counts[N_BARCODES])
-    if rank == 0 and int(counts.sum()) != n_reads * world:
-        raise RuntimeError(f"call histogram does not add up: {counts.sum()} != {n_reads * world}")
-    if rank == 0 and n_fail > 0.01 * n_reads * world:
-        raise RuntimeError(f"{n_fail} of {n_reads * world} reads failed: the synthetic workload should fingerprint cleanly")
+    if int(counts.sum()) != total:
+        raise RuntimeError(f"rank {rank}: all-reduced call histogram does not add up: {counts.sum()} != {total}")
+    if rank == 0 and n_fail > 0.01 * total:
+        raise RuntimeError(f"{n_fail} of {total} reads failed: the synthetic workload should fingerprint cleanly")
 
     # ---- roofline of the dominant kernel (algorithmic bytes, DESIGN.md "Measurement") ------------
-    n_ok = n_reads  # outputs are written for every read (NaN rows for failures)
-    fp_bytes = 4.0 * total_samples + 8.0 * K_FPT * n_ok + 4.0 * n_reads
+    steps = max(args.steps, 1)
+    fp_bytes = 4.0 * total_samples + 8.0 * K_FPT * n_reads + 4.0 * n_reads
     dtw_bytes = (8.0 * K_FPT + 4.0 * N_BARCODES + 4.0) * n_reads
     if fp_ms >= dtw_ms:
         dom, dom_ms, dom_n, dom_bytes = "fingerprint_fast_kernel", fp_ms, fp_n, fp_bytes
     else:
         dom, dom_ms, dom_n, dom_bytes = "dtw_band_kernel<15>", dtw_ms, dtw_n, dtw_bytes
+    launches_per_step = max(dom_n // steps, 1)
     avg_ms = dom_ms / max(dom_n, 1)
-    dom_bytes = dom_bytes / max(dom_n // max(args.steps, 1), 1)  # per kernel launch (a step may be sliced)
+    dom_bytes = dom_bytes / launches_per_step  # per kernel launch (a step may be sliced)
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic of that kernel from the PMC passes (profiles/traffic.json, written by
     # tools/collect_traffic.py on the same workload); null when not collected for this size
@@ -237,14 +525,13 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             tj = json.load(fh)
-        if tj.get("kernel") == dom and tj.get("reads_per_launch") == n_reads // max(dom_n // max(args.steps, 1), 1):
-            traffic = tj.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
+        if tj.get("kernel") == dom and tj.get("reads_per_step") == n_reads:
+            traffic = tj.get("hbm_bytes_per_step") / launches_per_step
+    except (OSError, ValueError, TypeError):
         pass
-
     valu_busy = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01i_sq_counters.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")) as fh:
             pl = json.load(fh)["kernels"][dom.split("<")[0]]["per_launch"]
         valu_busy = pl["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pl["GRBM_GUI_ACTIVE"] / 8.0)
     except (OSError, ValueError, KeyError):
@@ -252,8 +539,7 @@ def main():
 
     out = None
     if rank == 0:
-        reads_total = n_reads * world
-        value = reads_total * args.steps / elapsed
+        value = total * args.steps / elapsed
         fused_bytes_per_read = 4.0 * total_samples / n_reads + 4.0 * N_BARCODES + 4.0
         out = {
             "metric": "reads/sec demuxed (110-pt DTW x 10 barcodes)",
@@ -269,13 +555,17 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("C3: %d synthetic RNA004 adapter reads per GPU (wdx-synth v1, mean %.0f samples), "
+                "workload": ("%s: %d synthetic RNA004 adapter reads per GPU (%d in all; wdx-synth v1, mean %.0f samples), "
                              "WDX10 shape: 10 barcodes x 110-pt fingerprints, window 15, penalty 0.1; fused "
-                             "fingerprint+DTW+call+count, raw rows resident in HBM" % (n_reads, total_samples / n_reads)),
-                "reads_per_gpu": n_reads,
-                "reads_total": reads_total,
+                             "fingerprint+DTW+call+count, raw rows resident in HBM" % (workload, per_gpu, total, total_samples / n_reads)),
+                "reads_per_gpu": per_gpu,
+                "reads_total": total,
                 "failed_reads": n_fail,
-                "sharding": "contiguous read shards, one process per GPU, int64[11] count all-reduce per step",
+                "sharding": "contiguous shards of one global read range (dist.shard_range), one process per GPU, "
+                            "one int64[11] count all-reduce per step",
+                "count_allreduce": {"single": "none (one process)", "rccl": "wdx_reduce_counts (C ABI, RCCL)",
+                                    "torch": "torch.distributed.all_reduce (%s)" % (backend or "nccl")}[reducer.mode]
+                                   + (("; " + reducer.note) if reducer.note else ""),
             },
             "roofline": {
                 "bound": "hbm",
@@ -292,50 +582,65 @@ def main():
                 "valu_busy_frac": valu_busy,
             },
             "kernels_ms_per_step": {   # HIP-event sums over all launches of a step (a step may be sliced)
-                "fingerprint": fp_ms / max(args.steps, 1), "dtw": dtw_ms / max(args.steps, 1),
-                "transpose": tr_ms / max(args.steps, 1), "count": cnt_ms / max(args.steps, 1),
+                "fingerprint": fp_ms / steps, "dtw": dtw_ms / steps, "transpose": tr_ms / steps,
+                "count": cnt_ms / steps, "count_allreduce": red_ms / steps,
             },
             "fused_path": {
                 "algorithmic_bytes_per_read": fused_bytes_per_read,
                 "hbm_frac_whole_job_per_gpu": value / world * fused_bytes_per_read / 1e9 / HBM_PEAK_GBS,
-                "dtw_gcups_per_gpu": (n_reads * 29800.0) / (dtw_ms / max(dtw_n, 1) * 1e-3) / 1e9 if dtw_ms else None,
+                "dtw_gcups_per_gpu": (n_reads * float(N_BARCODES * CELLS_110)) / (dtw_ms / max(dtw_n, 1) * 1e-3) / 1e9 if dtw_ms else None,
             },
         }
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ------------------------------
+    # ---- CPU baseline + parity gate on a bounded sample (rank 0, N=1 only) ------------------------------
+    parity_failed = False
     if rank == 0 and world == 1 and not args.no_cpu:
-        ns = min(args.cpu_sample, n_reads)
-        end = int(off[ns].item())
-        sig_h = sig[:end].cpu().numpy()
-        off_h = off[: ns + 1].cpu().numpy()
-        multi, cores, single, parity, mb = cpu_baseline(
-            sig_h, off_h, a_s[:ns].cpu().numpy(), a_e[:ns].cpu().numpy(), refs,
-            res.call[:ns].cpu().numpy(), res.status[:ns].cpu().numpy(), res.dist[:ns].cpu().numpy())
-        out["cpu_baseline"] = {
-            "value": multi,
-            "unit": "reads/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "first %d reads of the same workload, oracle/wdx_oracle.c driven as %d-read minibatches over "
-                      "a ProcessPoolExecutor(%d) like file_proc.run_demux (IPC included); dtaidistance itself is "
-                      "not available" % (ns, mb, cores),
-            "single_core_value": single,
-        }
-        out["parity_on_sample"] = parity
-        if not parity:
-            print("ERROR: GPU results differ from the oracle on the CPU sample", file=sys.stderr)
+        cpu, parity = cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads,
+                                              args.cpu_seconds, args.parity_reads)
+        out["cpu_baseline"] = cpu
+        out["parity_gate"] = parity
+        out["parity_on_sample"] = parity["ok"]
+        parity_failed = not parity["ok"]
+        if parity_failed:
+            print("ERROR: GPU results differ from the oracle on the CPU sample: %r" % (parity,), file=sys.stderr)
+        ns = min(1000, n_reads)
+        g_fpt = eng.fingerprint(sig[: int(off[ns].item())], a_s[:ns], a_e[:ns], offsets=off[: ns + 1], max_len=max_len)[0]
+        fs = g_fpt.cpu().numpy()
+        out["dtaidistance"] = try_dtaidistance(eng, refs, fs[~np.isnan(fs).any(axis=1)])
     elif rank == 0:
         out["cpu_baseline"] = None
 
+    # ---- secondary regimes, after the big buffers are gone ----------------------------------------------
+    if rank == 0 and world == 1 and not args.no_secondary:
+        sig = off = a_s = a_e = bc = res = None
+        eng._work = None
+        torch.cuda.empty_cache()
+        sec = secondary_regimes(local_rank)
+        out["secondary"] = sec
+        for name, r in sec.items():
+            if isinstance(r, dict):
+                flags = [r.get("parity")] + [v.get("parity") for v in r.values() if isinstance(v, dict)]
+                if any(f is False for f in flags):
+                    parity_failed = True
+                    print(f"ERROR: secondary regime {name} differs from the oracle", file=sys.stderr)
+
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    reducer.close()
     eng.close()
     if world > 1:
         import torch.distributed as tdist
 
         tdist.destroy_process_group()
-    if out is not None and out.get("parity_on_sample") is False:
+    if parity_failed:
         sys.exit(2)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # nothing in this process has touched the GPU
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -19,8 +19,14 @@
  * the reference's ReadResult.success / fail_reason (sig_proc.py:26-62) and never fail the call.
  *
  * Threading: a context may be used from several threads (entry points serialise on it); create
- * one context per thread/stream for concurrency.  HIP is initialised lazily inside
- * wdx_ctx_create, so a process may fork (file_proc.py:1197) before creating its context.
+ * one context per thread/stream for concurrency (live_balancing/session.py:162-169 runs thread pools):
+ * every context owns a non-blocking HIP stream on which all of its host-buffer calls run, so calls
+ * through different contexts overlap on the device.  The workspaces of a context are ordered by stream
+ * order; when consecutive calls on one context name different streams the library waits for the earlier
+ * stream first.  HIP is initialised lazily inside wdx_ctx_create, so a process may fork
+ * (file_proc.py:1197-1243, ProcessPoolExecutor workers) before creating its context; a context must not
+ * be used in a child forked after its creation.  The caller's current HIP device is left unchanged by
+ * every entry point.  Nothing in the library reads the environment.
  */
 #ifndef WDX_H
 #define WDX_H
@@ -31,14 +37,14 @@
 extern "C" {
 #endif
 
-#define WDX_ABI_VERSION 1
+#define WDX_ABI_VERSION 2
 
 /* ---- call status ------------------------------------------------------------------------- */
 #define WDX_SUCCESS 0
 #define WDX_ERR_INVALID (-1)     /* bad argument (maps to ValueError in the Python shim)        */
 #define WDX_ERR_NO_DEVICE (-2)   /* no usable HIP device / runtime                              */
 #define WDX_ERR_HIP (-3)         /* a HIP call failed                                           */
-#define WDX_ERR_UNSUPPORTED (-4) /* legal in the reference, not implemented by this engine      */
+#define WDX_ERR_UNSUPPORTED (-4) /* legal in the reference, outside this engine's limits        */
 #define WDX_ERR_NO_REFS (-5)     /* a call that needs wdx_set_refs() came before it             */
 
 /* ---- per-read status (fingerprint stage); 0 == ReadResult.success ------------------------ */
@@ -65,6 +71,14 @@ typedef struct wdx_seg_params {
     int32_t accept_less_cpts;   /* segmentation.accept_less_cpts                                */
     int32_t seg_norm;           /* segmentation.normalization  (WDX_NORM_*)                     */
     int32_t barcode_num_events; /* segmentation.barcode_num_events (int form)                   */
+    /* How the clip bounds `med -/+ thresh*mad` (sig_proc.py:426-431) are evaluated -- the one place on the
+     * path where the reference's result depends on its NumPy: 0 = in float32 from outlier_thresh (NumPy >= 2
+     * promotion: float32 scalar x Python float stays float32); 1 = in float64 from outlier_thresh_f64 and
+     * rounded to float32 once (NumPy 1.x value-based promotion -- the reference pins numpy 1.26.4,
+     * environment.yml -- or an np.float64 threshold under NumPy 2).  The Python shim picks the rule of the
+     * NumPy it runs under, so the drop-in returns what the reference would have returned in that process. */
+    int32_t clip_bounds_f64;
+    double outlier_thresh_f64;  /* core.sig_norm_outlier_thresh as a double (used when clip_bounds_f64 != 0) */
 } wdx_seg_params;
 
 typedef struct wdx_ctx wdx_ctx;
@@ -78,8 +92,20 @@ int wdx_device_count(void);
 /* Create a context on HIP device `device`.  First HIP use in the process happens here. */
 int wdx_ctx_create(int device, wdx_ctx **out);
 void wdx_ctx_destroy(wdx_ctx *ctx);
-/* Block until all work enqueued through this context on `stream` has finished. */
+/* Block until all work enqueued through this context on `stream` (NULL = the context's own stream)
+ * has finished. */
 int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream);
+/* The context's own stream (hipStream_t as void*): the one its host-buffer calls run on. */
+int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
+
+/* Diagnostic switches (all 0 by default = the product path); used by tests and profiling tools only. */
+#define WDX_OPT_EXACT_PATH 1        /* fingerprint every read on the exact general kernel               */
+#define WDX_OPT_NO_WAVEFRONT_DTW 2  /* never dispatch the anti-diagonal DTW kernel                       */
+#define WDX_OPT_NO_SHORT_DTW 3      /* never dispatch the unrolled 25-point DTW kernel                   */
+#define WDX_OPT_SVM_SCALAR 4        /* scalar SVM tail kernel instead of the matrix-core one             */
+#define WDX_OPT_DEBUG_OCCUPANCY 5   /* print the fast fingerprint kernel's workgroups per CU to stderr   */
+#define WDX_OPT_FAST_PEAK_CAP 6     /* peak-list capacity of the fast fingerprint kernel (0 = built-in)  */
+int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,
  *      i.e. dtaidistance.dtw.distance_matrix(vstack[X,Y], block=((0,nX),(nX,nX+nY)),
@@ -155,11 +181,29 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
 /* Host-buffer form of the fused path (one call per minibatch or per live tick, one synchronisation):
  * fingerprint the (n_reads, stride) float32 minibatch, DTW every successful read against the resident
  * reference set (wdx_set_refs; K = p->barcode_num_events must equal its length), nearest-reference call.
+ * n_refs = the number of references the caller sized `dist` for; it must equal the resident nY
+ * (WDX_ERR_INVALID otherwise: another user of the context may have replaced the set).
  * Host outputs: status int32[n_reads]; call int32[n_reads] (argmin column, -1 for failed reads);
- * dist (n_reads, nY) float32 (nullable; NaN rows for failed reads); fpt (n_reads, K) float64 (nullable). */
+ * dist (n_reads, n_refs) float32 (nullable; NaN rows for failed reads); fpt (n_reads, K) float64 (nullable). */
 int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
                     const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
-                    const wdx_seg_params *p, double *fpt, float *dist, int32_t *call, int32_t *status);
+                    const wdx_seg_params *p, int64_t n_refs, double *fpt, float *dist, int32_t *call,
+                    int32_t *status);
+
+/* Live path (BASELINE config 5; N4): every read of one 100 ms chunk round in one call -- the batched form of
+ * live_balancing/worker.py:26-96 (segmentation_worker) + :99-131 (classification_worker).  rows[r] points at
+ * read r's float32 samples (row_len[r] of them; ragged, caller-owned, only the adapter window
+ * [max(0, a_start-padding), min(row_len, a_end+padding)) is read -- the live caller passes a_start = 0 and
+ * a_end = polya_start, worker.py:39-44).  The windows are packed into a page-locked staging block, copied
+ * once, run through fingerprint -> DTW against the resident references [-> SVM tail when use_svm != 0 and a
+ * model trained on those references is resident] on the context's own stream, and the requested outputs
+ * come back in one copy; one synchronisation per call.  Outputs are HOST pointers: status int32[n] is
+ * required; call int32[n], dist (n, n_refs) float32, fpt (n, K) float64, prob (n, k) float64,
+ * pred int32[n] (barcode label or -1 = outlier, worker.py:125), conf float64[n] are nullable. */
+int wdx_live_tick(wdx_ctx *ctx, const float *const *rows, const int32_t *row_len, int64_t n_reads,
+                  const int32_t *a_start, const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
+                  int64_t n_refs, int32_t use_svm, double *fpt, float *dist, int32_t *call, int32_t *status,
+                  double *prob, int32_t *pred, double *conf);
 
 /* ---- N1: classifier tail of DTW_SVM.predict (models/dtw_svm.py:90-93 + models/utils.py:45-61):
  *      K = exp(-gamma * d^pwr_dist) -> SVC.predict_proba(K) (libsvm, precomputed kernel) -> argmax,
@@ -188,6 +232,26 @@ int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_
  * set (wdx_set_refs with model._X, window, penalty) -> SVM tail.  Outputs host, nullable. */
 int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf);
 
+/* ---- multi-GPU: the only exchange on the path ---------------------------------------
+ * Reads shard over one process per GPU with no data-path collective; after the last batch the per-barcode
+ * call histogram -- the engine's form of the reference's shared run counters `ridx_dict`
+ * (file_proc.py:1059-1066) -- is summed over ranks by ONE RCCL all-reduce (xGMI within a node).
+ * librccl is dlopen'ed on first use (the copy already loaded in the process, e.g. PyTorch's, is
+ * preferred), so a single-GPU user never needs it. */
+#define WDX_COMM_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+/* Rank 0 creates the rendezvous id and hands the 128 bytes to the other ranks by any means (the
+ * launcher's store, a file, MPI ...).  Needs no context. */
+int wdx_comm_unique_id(void *id_out /* WDX_COMM_ID_BYTES */);
+/* Collective over all `world` ranks: bind the context to rank `rank` of the communicator `id`. */
+int wdx_comm_init(wdx_ctx *ctx, const void *id, int32_t rank, int32_t world);
+int wdx_comm_destroy(wdx_ctx *ctx);
+/* In-place SUM all-reduce of d_counts int64[n] (DEVICE pointer, e.g. wdx_demux_dev's d_counts) over the
+ * communicator, enqueued on `stream`; no synchronisation.  Without a communicator (single process) it is
+ * a no-op that returns WDX_SUCCESS. */
+int wdx_reduce_counts(wdx_ctx *ctx, int64_t *d_counts, int32_t n, void *stream);
+/* Host-buffer form: counts int64[n] on the host, reduced in place; synchronises. */
+int wdx_reduce_counts_host(wdx_ctx *ctx, int64_t *counts, int32_t n);
+
 /* ---- measurement helpers ------------------------------------------------------------------ */
 
 /* Kernel ids for wdx_kernel_time */
@@ -196,6 +260,7 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
 #define WDX_K_TRANSPOSE 2
 #define WDX_K_COUNT 3
 #define WDX_K_SVM 4
+#define WDX_K_REDUCE 5
 /* When enabled, every kernel launch through this context is bracketed by hipEvents on its
  * stream; wdx_kernel_time() synchronises them and returns accumulated ms and launch count. */
 int wdx_kernel_timing(wdx_ctx *ctx, int enable);

@@ -40,7 +40,52 @@ typedef struct {
     int32_t accept_less_cpts;   /* segmentation.accept_less_cpts                               */
     int32_t seg_norm;           /* segmentation.normalization: 0 none, 1 mean, 2 median        */
     int32_t barcode_num_events; /* segmentation.barcode_num_events (int form)                  */
+    int32_t clip_bounds_f64;    /* how `med -/+ thresh*mad` (sig_proc.py:426-431) is evaluated: 0 = in float32
+                                   (NumPy >= 2 promotion with a Python-float threshold: the build container),
+                                   1 = in float64 from outlier_thresh_f64, rounded to float32 once (NumPy 1.x --
+                                   the reference pins 1.26.4, environment.yml -- or an np.float64 threshold)   */
+    double outlier_thresh_f64;  /* the threshold as a double (used when clip_bounds_f64 != 0)    */
 } wdx_seg_params;
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-thread scratch arena for the fingerprint chain                                         */
+/* ------------------------------------------------------------------------------------------ */
+/* The CPU baseline drives this file from one thread per host core (bench.py); a dozen malloc/free pairs of
+ * tens of KB per read from 256 threads serialise on the process's address-space lock (heap trimming, page
+ * faults on re-grown tops).  Every temporary of one read therefore comes from a thread-local block that is
+ * sized once per exported call and rewound when the call returns; requests that do not fit fall through
+ * to malloc. */
+static __thread char *t_arena = NULL;
+static __thread size_t t_cap = 0, t_top = 0;
+
+static void *a_alloc(size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    if (t_arena && t_top + n <= t_cap) {
+        void *p = t_arena + t_top;
+        t_top += n;
+        return p;
+    }
+    return malloc(n);
+}
+
+static void a_free(void *p) {
+    if (!p) return;
+    if (t_arena && (char *)p >= t_arena && (char *)p < t_arena + t_cap) return;
+    free(p);
+}
+
+/* call at the top of an exported function with the largest vector length it will see */
+static size_t a_enter(int64_t n) {
+    size_t est = (size_t)160 * ((size_t)(n > 0 ? n : 0) + 1024);
+    if (t_top == 0 && t_cap < est) {
+        free(t_arena);
+        t_arena = (char *)malloc(est);
+        t_cap = t_arena ? est : 0;
+    }
+    return t_top;
+}
+
+static void a_leave(size_t mark) { t_top = mark; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* small selection / sorting helpers                                                          */
@@ -123,7 +168,82 @@ static double np_pairwise_sum(const double *a, int64_t n) {
     }
 }
 
-static double np_mean_f64(const double *a, int64_t n) { return np_pairwise_sum(a, n) / (double)n; }
+/* add.reduce over a contiguous vector: the ufunc machinery hands the inner loop at most `bufsize`
+ * (np.getbufsize() = 8192) elements at a time, so the result is pairwise(chunk0) + pairwise(chunk1) + ...
+ * accumulated left to right (probed against NumPy 2.2.6: n = 8192 is one pairwise tree, n = 8193 is not). */
+#define NP_BUFSIZE 8192
+static double np_add_reduce_f64(const double *a, int64_t n) {
+    double res = np_pairwise_sum(a, n < NP_BUFSIZE ? n : NP_BUFSIZE);
+    for (int64_t c = NP_BUFSIZE; c < n; c += NP_BUFSIZE)
+        res += np_pairwise_sum(a + c, n - c < NP_BUFSIZE ? n - c : NP_BUFSIZE);
+    return res;
+}
+
+static double np_mean_f64(const double *a, int64_t n) { return np_add_reduce_f64(a, n) / (double)n; }
+
+/* the same routine instantiated for float32 (FLOAT_pairwise_sum): np.mean / np.std of a float32 array
+ * accumulate in float32 (numpy/_core/_methods.py::_mean keeps the input dtype for float32) */
+static float np_pairwise_sum_f32(const float *a, int64_t n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8];
+        int64_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+static float np_add_reduce_f32(const float *a, int64_t n) {
+    float res = np_pairwise_sum_f32(a, n < NP_BUFSIZE ? n : NP_BUFSIZE);
+    for (int64_t c = NP_BUFSIZE; c < n; c += NP_BUFSIZE)
+        res += np_pairwise_sum_f32(a + c, n - c < NP_BUFSIZE ? n - c : NP_BUFSIZE);
+    return res;
+}
+
+/* mean_normalize on a float32 vector, sig_proc.py:99-111 (in place).  No NaN: np.mean / np.std
+ * (_methods.py::_mean, _var: float32 pairwise sums, float32 divisions by the count, float32 sqrt).
+ * With NaN (accept_nan=True): np.nanmean / np.nanstd (_nanfunctions_impl.py: NaN -> 0 copies, sums in
+ * float32, `_divide_by_count` = true_divide(float32, intp, out=float32, casting="unsafe"), i.e. the
+ * quotient is formed in float64 and rounded to float32). scratch: n floats. */
+static void mean_normalize_f32(float *x, int64_t n, float *scratch) {
+    int has_nan = 0;
+    for (int64_t i = 0; i < n; i++) has_nan |= (x[i] != x[i]);
+    float shift, scale;
+    if (!has_nan) {
+        shift = np_add_reduce_f32(x, n) / (float)n;
+        for (int64_t i = 0; i < n; i++) {
+            float d = x[i] - shift;
+            scratch[i] = d * d;
+        }
+        scale = sqrtf(np_add_reduce_f32(scratch, n) / (float)n);
+    } else {
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int isn = x[i] != x[i];
+            scratch[i] = isn ? 0.0f : x[i];
+            cnt += !isn;
+        }
+        shift = (float)((double)np_add_reduce_f32(scratch, n) / (double)cnt);
+        for (int64_t i = 0; i < n; i++) {
+            float d = scratch[i] - shift;      /* np.subtract(arr, avg, out=arr) on the NaN->0 copy   */
+            if (x[i] != x[i]) d = 0.0f;        /* _copyto(arr, 0, mask)                               */
+            scratch[i] = d * d;
+        }
+        scale = sqrtf((float)((double)np_add_reduce_f32(scratch, n) / (double)cnt));
+    }
+    for (int64_t i = 0; i < n; i++) x[i] = (x[i] - shift) / scale;
+}
 
 /* np.std(ddof=0): numpy/_core/_methods.py::_var -> sqrt */
 static double np_std_f64(const double *a, int64_t n, double *scratch) {
@@ -132,7 +252,7 @@ static double np_std_f64(const double *a, int64_t n, double *scratch) {
         double d = a[i] - mean;
         scratch[i] = d * d;
     }
-    return sqrt(np_pairwise_sum(scratch, n) / (double)n);
+    return sqrt(np_add_reduce_f64(scratch, n) / (double)n);
 }
 
 /* Python round(): float -> nearest int, ties to even (used at sig_proc.py:528,532) */
@@ -216,13 +336,13 @@ static void stable_argsort(const double *key, int64_t n, int64_t *order, int64_t
 
 /* find_peaks(x, distance): local maxima + _select_by_peak_distance (priority = height).
  * peaks_out must hold n/2+1 entries. Returns number of kept peaks (ascending positions). */
-int64_t wdx_oracle_find_peaks(const double *x, int64_t n, int64_t distance, int64_t *peaks_out) {
+static int64_t wdx_oracle_find_peaks_impl(const double *x, int64_t n, int64_t distance, int64_t *peaks_out) {
     if (n < 3) return 0;
     int64_t cap = n / 2 + 2;
-    int64_t *peaks = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap * 3);
+    int64_t *peaks = (int64_t *)a_alloc(sizeof(int64_t) * (size_t)cap * 3);
     int64_t *order = peaks + cap, *tmp = order + cap;
-    double *prio = (double *)malloc(sizeof(double) * (size_t)cap);
-    unsigned char *keep = (unsigned char *)malloc((size_t)cap);
+    double *prio = (double *)a_alloc(sizeof(double) * (size_t)cap);
+    unsigned char *keep = (unsigned char *)a_alloc((size_t)cap);
     int64_t np_ = local_maxima_1d(x, n, peaks);
     for (int64_t i = 0; i < np_; i++) {
         prio[i] = x[peaks[i]];
@@ -240,24 +360,30 @@ int64_t wdx_oracle_find_peaks(const double *x, int64_t n, int64_t distance, int6
     int64_t m = 0;
     for (int64_t i = 0; i < np_; i++)
         if (keep[i]) peaks_out[m++] = peaks[i];
-    free(peaks);
-    free(prio);
-    free(keep);
+    a_free(peaks);
+    a_free(prio);
+    a_free(keep);
     return m;
+}
+int64_t wdx_oracle_find_peaks(const double *x, int64_t n, int64_t distance, int64_t *peaks_out) {
+    size_t mark_ = a_enter(n);
+    int64_t r_ = wdx_oracle_find_peaks_impl(x, n, distance, peaks_out);
+    a_leave(mark_);
+    return r_;
 }
 
 /* discrepenacy_curve_to_cpts  (sig_proc.py:176-198).
  * cpts must hold num_events+2 entries.  Returns the number of boundaries written, 0 for the
  * "return np.array([])" branch, -1 when the reference would raise (distance < 1 in find_peaks,
  * or indexing an empty array). */
-int64_t wdx_oracle_scores_to_cpts(const double *scores, int64_t n_scores, int64_t num_events,
+static int64_t wdx_oracle_scores_to_cpts_impl(const double *scores, int64_t n_scores, int64_t num_events,
                                   int64_t min_obs_per_base, int64_t running_stat_width,
                                   int accept_less_cpts, int64_t *cpts) {
     if (min_obs_per_base < 1) return -1; /* scipy: "`distance` must be greater or equal to 1" */
     int64_t cap = n_scores / 2 + 2;
-    int64_t *peaks = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap * 3);
+    int64_t *peaks = (int64_t *)a_alloc(sizeof(int64_t) * (size_t)cap * 3);
     int64_t *order = peaks + cap, *tmp = order + cap;
-    double *h = (double *)malloc(sizeof(double) * (size_t)cap);
+    double *h = (double *)a_alloc(sizeof(double) * (size_t)cap);
     int64_t np_ = wdx_oracle_find_peaks(scores, n_scores, min_obs_per_base, peaks);
     int64_t ret;
     if (np_ < num_events && !accept_less_cpts) {
@@ -277,12 +403,18 @@ int64_t wdx_oracle_scores_to_cpts(const double *scores, int64_t n_scores, int64_
             if (sel[i]) cpts[m++] = peaks[i] + running_stat_width;
         int64_t signal_len = n_scores + 2 * running_stat_width;
         if (cpts[m - 1] != signal_len) cpts[m++] = signal_len;
-        free(sel);
+        a_free(sel);
         ret = m;
     }
-    free(peaks);
-    free(h);
+    a_free(peaks);
+    a_free(h);
     return ret;
+}
+int64_t wdx_oracle_scores_to_cpts(const double *scores, int64_t n_scores, int64_t num_events, int64_t min_obs_per_base, int64_t running_stat_width, int accept_less_cpts, int64_t *cpts) {
+    size_t mark_ = a_enter(n_scores);
+    int64_t r_ = wdx_oracle_scores_to_cpts_impl(scores, n_scores, num_events, min_obs_per_base, running_stat_width, accept_less_cpts, cpts);
+    a_leave(mark_);
+    return r_;
 }
 
 /* A5: c_new_means (segmentation/_c_segmentation.pyx:41-53) */
@@ -303,7 +435,7 @@ void wdx_oracle_new_means(const double *x, const int64_t *segs, int64_t n_segs, 
  * Outputs: fpt[K], dwell[K], stats[6] = {dt_med, dt_mad, event_mean, event_std, event_med,
  * event_mad}; optional debug outputs (may be NULL): cpts_out[num_events+2] & n_cpts_out.
  * Returns a WDX_* status. On failure outputs are left untouched. */
-int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_start, int32_t a_end,
+static int wdx_oracle_fingerprint_one_impl(const float *row, int64_t row_len, int32_t a_start, int32_t a_end,
                                int ok, const wdx_seg_params *p, double *fpt, int64_t *dwell,
                                double *stats, int64_t *cpts_out, int64_t *n_cpts_out) {
     if (n_cpts_out) *n_cpts_out = 0;
@@ -316,25 +448,33 @@ int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_star
     int64_t n = stop - start;
     if (n < 0) n = 0; /* empty python slice */
     int status = WDX_OK;
-    float *sig = (float *)malloc(sizeof(float) * (size_t)(n + 1) * 2);
+    float *sig = (float *)a_alloc(sizeof(float) * (size_t)(n + 1) * 2);
     float *scratch = sig + n + 1;
-    double *x = (double *)malloc(sizeof(double) * (size_t)(n + 1) * 2);
+    double *x = (double *)a_alloc(sizeof(double) * (size_t)(n + 1) * 2);
     double *scores = x + n + 1;
     int64_t E = p->num_events;
-    int64_t *cpts = (int64_t *)malloc(sizeof(int64_t) * (size_t)(E + 2));
-    double *ev = (double *)malloc(sizeof(double) * (size_t)(E + 2) * 4);
+    int64_t *cpts = (int64_t *)a_alloc(sizeof(int64_t) * (size_t)(E + 2));
+    double *ev = (double *)a_alloc(sizeof(double) * (size_t)(E + 2) * 4);
     double *z = ev + (E + 2), *tmp = z + (E + 2), *tmp2 = tmp + (E + 2);
     memcpy(sig, row + start, sizeof(float) * (size_t)n);
 
     /* A1 MAD outlier clip, sig_proc.py:421-431 (float32 throughout under NumPy>=2 promotion) */
     float med = nanmedian_f32(sig, n, scratch);
     {
-        float *dev = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+        float *dev = (float *)a_alloc(sizeof(float) * (size_t)(n + 1));
         for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - med);
         float mad = nanmedian_f32(dev, n, scratch);
-        free(dev);
-        float tm = p->outlier_thresh * mad;
-        float lo = med - tm, hi = med + tm;
+        a_free(dev);
+        float lo, hi;
+        if (p->clip_bounds_f64) {
+            double tm = p->outlier_thresh_f64 * (double)mad;
+            lo = (float)((double)med - tm);
+            hi = (float)((double)med + tm);
+        } else {
+            float tm = p->outlier_thresh * mad;
+            lo = med - tm;
+            hi = med + tm;
+        }
         for (int64_t i = 0; i < n; i++) {
             /* np.clip == minimum(maximum(x, lo), hi) with NaN propagation */
             float v = sig[i];
@@ -352,16 +492,13 @@ int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_star
         int has_nan = 0;
         for (int64_t i = 0; i < n; i++) has_nan |= (sig[i] != sig[i]);
         if (p->sig_norm == 1) {
-            /* mean_normalize on float32 (np.mean/np.std resp. nanmean/nanstd, float32 pairwise).
-             * Not restated: no shipped config uses it. */
-            status = WDX_FAIL_SIGNORM;
-            goto done;
+            mean_normalize_f32(sig, n, scratch);
         } else if (p->sig_norm == 2) {
             float shift = nanmedian_f32(sig, n, scratch);
-            float *dev = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+            float *dev = (float *)a_alloc(sizeof(float) * (size_t)(n + 1));
             for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - shift);
             float scale = nanmedian_f32(dev, n, scratch);
-            free(dev);
+            a_free(dev);
             (void)has_nan; /* nan- and plain medians agree when there is no NaN */
             for (int64_t i = 0; i < n; i++) sig[i] = (sig[i] - shift) / scale;
         } else {
@@ -438,11 +575,116 @@ int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_star
         stats[3] = ev_std; stats[4] = ev_med; stats[5] = ev_mad;
     }
 done:
-    free(sig);
-    free(x);
-    free(cpts);
-    free(ev);
+    a_free(sig);
+    a_free(x);
+    a_free(cpts);
+    a_free(ev);
     return status;
+}
+int wdx_oracle_fingerprint_one(const float *row, int64_t row_len, int32_t a_start, int32_t a_end, int ok, const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats, int64_t *cpts_out, int64_t *n_cpts_out) {
+    size_t mark_ = a_enter((int64_t)a_end - a_start + 2 * (int64_t)p->padding);
+    int r_ = wdx_oracle_fingerprint_one_impl(row, row_len, a_start, a_end, ok, p, fpt, dwell, stats, cpts_out, n_cpts_out);
+    a_leave(mark_);
+    return r_;
+}
+
+/* ---- the normalisation helpers on their own (fixture G5 pins them against the reference's functions) ---- */
+
+/* normalize(signal float64 1-D, method, accept_nan=False) for a NaN-free vector, sig_proc.py:114-136:
+ * method 1 = mean_normalize (np.mean / np.std), 2 = mad_normalize (np.median, np.median(|x - med|)). */
+static int wdx_oracle_normalize_f64_impl(const double *x, int64_t n, int method, double *out) {
+    if (n == 0) return 0;
+    double *tmp = (double *)a_alloc(sizeof(double) * (size_t)n * 2);
+    double shift, scale;
+    if (method == 1) {
+        shift = np_mean_f64(x, n);
+        scale = np_std_f64(x, n, tmp);
+    } else if (method == 2) {
+        shift = median_f64(x, n, tmp);
+        for (int64_t i = 0; i < n; i++) tmp[n + i] = fabs(x[i] - shift);
+        scale = median_f64(tmp + n, n, tmp);
+    } else {
+        a_free(tmp);
+        return -1;
+    }
+    for (int64_t i = 0; i < n; i++) out[i] = (x[i] - shift) / scale;
+    a_free(tmp);
+    return 0;
+}
+int wdx_oracle_normalize_f64(const double *x, int64_t n, int method, double *out) {
+    size_t mark_ = a_enter(n);
+    int r_ = wdx_oracle_normalize_f64_impl(x, n, method, out);
+    a_leave(mark_);
+    return r_;
+}
+
+/* normalize(signal float32 1-D, method, accept_nan=True) as stage A2 applies it (sig_proc.py:433-437) */
+static int wdx_oracle_normalize_f32_impl(const float *x, int64_t n, int method, float *out) {
+    if (n == 0) return 0;
+    float *scratch = (float *)a_alloc(sizeof(float) * (size_t)(n + 1) * 2);
+    memcpy(out, x, sizeof(float) * (size_t)n);
+    if (method == 1) {
+        mean_normalize_f32(out, n, scratch);
+    } else if (method == 2) {
+        float shift = nanmedian_f32(x, n, scratch);
+        float *dev = scratch + n + 1;
+        for (int64_t i = 0; i < n; i++) dev[i] = fabsf(x[i] - shift);
+        float scale = nanmedian_f32(dev, n, scratch);
+        for (int64_t i = 0; i < n; i++) out[i] = (x[i] - shift) / scale;
+    } else if (method != 0) {
+        a_free(scratch);
+        return -1;
+    }
+    a_free(scratch);
+    return 0;
+}
+int wdx_oracle_normalize_f32(const float *x, int64_t n, int method, float *out) {
+    size_t mark_ = a_enter(n);
+    int r_ = wdx_oracle_normalize_f32_impl(x, n, method, out);
+    a_leave(mark_);
+    return r_;
+}
+
+/* med = np.nanmedian(x), mad = np.nanmedian(|x - med|) on float32 (stage A1, sig_proc.py:421-422) */
+static void wdx_oracle_nanmedian_mad_f32_impl(const float *x, int64_t n, float *med, float *mad) {
+    float *scratch = (float *)a_alloc(sizeof(float) * (size_t)(n + 1) * 2);
+    float *dev = scratch + n + 1;
+    *med = nanmedian_f32(x, n, scratch);
+    for (int64_t i = 0; i < n; i++) dev[i] = fabsf(x[i] - *med);
+    *mad = nanmedian_f32(dev, n, scratch);
+    a_free(scratch);
+}
+void wdx_oracle_nanmedian_mad_f32(const float *x, int64_t n, float *med, float *mad) {
+    size_t mark_ = a_enter(n);
+    wdx_oracle_nanmedian_mad_f32_impl(x, n, med, mad);
+    a_leave(mark_);
+}
+
+/* normalize_wrt(to_norm 1-D float64, ref 1-D float64, method), sig_proc.py:139-168 */
+static int wdx_oracle_normalize_wrt_impl(const double *to_norm, int64_t m, const double *ref, int64_t n, int method,
+                             double *out) {
+    double *tmp = (double *)a_alloc(sizeof(double) * (size_t)(n + 1) * 2);
+    double shift, scale;
+    if (method == 1) {
+        shift = np_mean_f64(ref, n);
+        scale = np_std_f64(ref, n, tmp);
+    } else if (method == 2) {
+        shift = median_f64(ref, n, tmp);
+        for (int64_t i = 0; i < n; i++) tmp[n + 1 + i] = fabs(ref[i] - shift);
+        scale = median_f64(tmp + n + 1, n, tmp);
+    } else {
+        a_free(tmp);
+        return -1;
+    }
+    for (int64_t i = 0; i < m; i++) out[i] = (to_norm[i] - shift) / scale;
+    a_free(tmp);
+    return 0;
+}
+int wdx_oracle_normalize_wrt(const double *to_norm, int64_t m, const double *ref, int64_t n, int method, double *out) {
+    size_t mark_ = a_enter(n);
+    int r_ = wdx_oracle_normalize_wrt_impl(to_norm, m, ref, n, method, out);
+    a_leave(mark_);
+    return r_;
 }
 
 /* batch driver mirroring the per-read loop at file_proc.py:418-428 */

@@ -36,6 +36,8 @@ class SegParamsC(C.Structure):
         ("accept_less_cpts", C.c_int32),
         ("seg_norm", C.c_int32),
         ("barcode_num_events", C.c_int32),
+        ("clip_bounds_f64", C.c_int32),
+        ("outlier_thresh_f64", C.c_double),
     ]
 
 
@@ -52,12 +54,14 @@ class SegParams:
     accept_less_cpts: bool = False
     seg_norm: str = "mean"
     barcode_num_events: int = 25
+    clip_bounds_f64: bool = False   # True = NumPy 1.x promotion (the reference's pinned 1.26.4) / np.float64 threshold
 
     def to_c(self) -> SegParamsC:
         return SegParamsC(
             self.padding, NORM_CODES[self.sig_norm], self.outlier_thresh, self.min_obs_per_base,
             self.running_stat_width, self.num_events, int(self.accept_less_cpts),
-            NORM_CODES[self.seg_norm], self.barcode_num_events,
+            NORM_CODES[self.seg_norm], self.barcode_num_events, int(self.clip_bounds_f64),
+            float(self.outlier_thresh),
         )
 
 
@@ -87,6 +91,14 @@ def lib():
         L.wdx_oracle_new_means.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.wdx_oracle_fingerprint_one.restype = C.c_int
         L.wdx_oracle_fingerprint_one.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_normalize_f64.restype = C.c_int
+        L.wdx_oracle_normalize_f64.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.wdx_oracle_normalize_f32.restype = C.c_int
+        L.wdx_oracle_normalize_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.wdx_oracle_nanmedian_mad_f32.restype = None
+        L.wdx_oracle_nanmedian_mad_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_normalize_wrt.restype = C.c_int
+        L.wdx_oracle_normalize_wrt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.wdx_oracle_fingerprint_batch.restype = C.c_int
         L.wdx_oracle_fingerprint_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wdx_oracle_fingerprint_packed.restype = C.c_int
@@ -135,6 +147,38 @@ def new_means(x, segs) -> np.ndarray:
     segs = np.ascontiguousarray(segs, dtype=np.int64)
     out = np.empty(segs.size - 1, dtype=np.float64)
     lib().wdx_oracle_new_means(_p(x), _p(segs), segs.size - 1, _p(out))
+    return out
+
+
+def normalize(x, method="mean"):
+    """sig_proc.normalize on a 1-D vector: float64 (NaN-free, accept_nan=False semantics) or float32
+    (stage A2: accept_nan=True semantics)."""
+    x = np.ascontiguousarray(x)
+    if x.dtype == np.float32:
+        out = np.empty_like(x)
+        rc = lib().wdx_oracle_normalize_f32(_p(x), x.size, NORM_CODES[method], _p(out))
+    else:
+        x = x.astype(np.float64, copy=False)
+        out = np.empty_like(x)
+        rc = lib().wdx_oracle_normalize_f64(_p(x), x.size, NORM_CODES[method], _p(out))
+    if rc:
+        raise ValueError(f"Normalization method {method} not recognized.")
+    return out
+
+
+def nanmedian_mad_f32(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    med, mad = C.c_float(0), C.c_float(0)
+    lib().wdx_oracle_nanmedian_mad_f32(_p(x), x.size, C.byref(med), C.byref(mad))
+    return np.float32(med.value), np.float32(mad.value)
+
+
+def normalize_wrt(to_norm, ref, method="mean"):
+    to_norm = np.ascontiguousarray(to_norm, dtype=np.float64)
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    out = np.empty_like(to_norm)
+    if lib().wdx_oracle_normalize_wrt(_p(to_norm), to_norm.size, _p(ref), ref.size, NORM_CODES[method], _p(out)):
+        raise ValueError(f"Normalization method {method} not recognized.")
     return out
 
 

@@ -203,6 +203,9 @@ def main():
              int(p.segmentation.accept_less_cpts), {"none": 0, "mean": 1, "median": 2}[p.segmentation.normalization],
              K], dtype=np.int64)
         g4[f"thresh_{k}"] = np.float64(p.core.sig_norm_outlier_thresh)
+        # an np.float64 threshold makes NumPy >= 2 evaluate `med -/+ thresh*mad` in float64 and np.clip round the
+        # bound to float32 once -- what NumPy 1.x (the reference's pinned 1.26.4) does with a Python float too
+        g4[f"clip64_{k}"] = np.int64(isinstance(p.core.sig_norm_outlier_thresh, np.float64))
         g4[f"status_{k}"] = np.int64(st)
         g4[f"fpt_{k}"] = fpt
         g4[f"dwell_{k}"] = dwell
@@ -227,6 +230,20 @@ def main():
         run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_segnorm_none", seg_norm="none")
     for i in range(2):
         run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_signorm_median", sig_norm="median")
+    # sig_extract.normalization = "mean" (sig_proc.py:99-111 on the float32 adapter signal)
+    for i in range(4):
+        run_case(mb[i], int(a_s[i]), int(a_e[i]), tag="synth_signorm_mean", sig_norm="mean")
+    run_case(mb[8], int(a_s[8]), int(a_e[8]), tag="synth_signorm_mean_K110", sig_norm="mean", K=110)
+    run_case(mb[9], int(a_s[9]), int(a_e[9]), tag="synth_signorm_mean_thresh3", sig_norm="mean", thresh=3.0)
+    # float64 clip bounds (NumPy 1.x promotion, emulated with an np.float64 threshold); thresholds that are not
+    # small integers make the float32 and float64 evaluations of the bound differ
+    for i in range(6):
+        run_case(mb[10 + i], int(a_s[10 + i]), int(a_e[10 + i]), tag="synth_clip64_2.7", thresh=np.float64(2.7))
+    for i in range(4):
+        run_case(mb[10 + i], int(a_s[10 + i]), int(a_e[10 + i]), tag="synth_clip32_2.7", thresh=2.7)
+    for i in range(2):
+        run_case(mb[16 + i], int(a_s[16 + i]), int(a_e[16 + i]), tag="synth_clip64_5.0", thresh=np.float64(5.0))
+    run_case(mb[18], int(a_s[18]), int(a_e[18]), tag="synth_clip64_3.3_K110", thresh=np.float64(3.3), K=110)
     # detect failure passthrough
     run_case(mb[0], 100, 4000, ok=False, tag="detect_failed")
     # NaN-tailed row: adapter_end + padding reaches into the NaN tail
@@ -260,6 +277,9 @@ def main():
     nm = mb[5].copy()
     nm[2000:2003] = np.nan
     run_case(nm, int(a_s[5]), int(a_e[5]), tag="nan_middle")
+    # NaNs + "mean" signal normalisation: nanmean / nanstd branch (accept_nan=True, sig_proc.py:433-437)
+    run_case(nm, int(a_s[5]), int(a_e[5]), tag="nan_middle_signorm_mean", sig_norm="mean")
+    run_case(mb[1], int(a_s[1]), ln + 50, tag="nan_tail_signorm_mean", sig_norm="mean")
     # accept_less_cpts
     run_case(rng.normal(90, 1, 1400).astype(np.float32), 0, 1400, tag="accept_less_few", padding=0, accept_less=True)
     run_case(mb[6], int(a_s[6]), int(a_e[6]), tag="accept_less_enough", accept_less=True)
@@ -298,6 +318,31 @@ def main():
             mad = np.nanmedian(np.abs(a_nan - med))
         g5[f"f32_med_{k}"] = np.float32(med)
         g5[f"f32_mad_{k}"] = np.float32(mad)
+        k += 1
+    # float32 vectors through normalize(..., accept_nan=True) as stage A2 calls it, with and without NaN
+    for n in (1, 2, 7, 8, 9, 127, 128, 129, 257, 1000, 4801, 9973):
+        a = rng.normal(80, 12, n).astype(np.float32)
+        for with_nan in (False, True):
+            b = a.copy()
+            if with_nan:
+                if n < 3:
+                    continue
+                b[rng.integers(0, n, max(1, n // 10))] = np.nan
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                g5[f"n32_{k}"] = b
+                g5[f"n32_mean_{k}"] = sp.normalize(b.copy(), "mean", accept_nan=True)
+                g5[f"n32_median_{k}"] = sp.normalize(b.copy(), "median", accept_nan=True)
+            assert g5[f"n32_mean_{k}"].dtype == np.float32
+            k += 1
+    # normalize_wrt (sig_proc.py:139-168): float64 event means against a float64 reference vector
+    for m, n in ((1, 5), (25, 84), (40, 121), (7, 300)):
+        t = rng.normal(0, 1, m)
+        r = rng.normal(0.3, 1.2, n)
+        g5[f"wrt_t_{k}"] = t
+        g5[f"wrt_r_{k}"] = r
+        g5[f"wrt_mean_{k}"] = np.asarray(sp.normalize_wrt(t, r, "mean"), dtype=np.float64).reshape(-1)
+        g5[f"wrt_median_{k}"] = np.asarray(sp.normalize_wrt(t, r, "median"), dtype=np.float64).reshape(-1)
         k += 1
     g5["n"] = np.int64(k)
     np.savez_compressed(os.path.join(HERE, "g5_normalize.npz"), **g5)

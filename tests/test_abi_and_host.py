@@ -24,16 +24,16 @@ def test_header_symbols_are_exported():
     L = _lib.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.wdx_abi_version() == 1
+    assert L.wdx_abi_version() == 2
 
 
 def test_seg_params_struct_layout_matches_header():
     hdr = open(os.path.join(ROOT, "include", "wdx.h")).read()
     body = hdr[hdr.index("typedef struct wdx_seg_params {"): hdr.index("} wdx_seg_params;")]
-    fields = re.findall(r"^\s*(int32_t|float)\s+(\w+);", body, flags=re.M)
+    fields = re.findall(r"^\s*(int32_t|float|double)\s+(\w+);", body, flags=re.M)
     assert [f[1] for f in fields] == [f[0] for f in _lib.SegParamsC._fields_]
     import ctypes
-    assert ctypes.sizeof(_lib.SegParamsC) == 36
+    assert ctypes.sizeof(_lib.SegParamsC) == 48
 
 
 def test_no_silent_fallback_without_gpu():
@@ -107,3 +107,36 @@ def test_shard_ranges_partition_the_reads():
             assert max(hi - lo for lo, hi in parts) <= -(-n // world)
     with pytest.raises(ValueError):
         dist.shard_range(10, 2, 2)
+
+
+def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment starts N ranks itself, as children, before any
+    GPU call in the parent (the driver invokes bench.py exactly like that)."""
+    import importlib
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert "torch" not in bench.main.__code__.co_names   # the launcher path imports no torch
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

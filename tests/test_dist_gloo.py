@@ -44,7 +44,10 @@ def _worker(rank, world, port, n_total, out_q):
     counts = torch.from_numpy(np.bincount(call, minlength=5).astype(np.int64))
     local = counts.clone()
     dist.barrier()
-    dist.reduce_counts(counts)
+    red = dist.CountReducer(None)          # no GPU context here: the process-group road of the shim
+    assert red.mode == "torch"
+    red(counts)
+    assert dist.min_over_ranks(float(rank + 1)) == 1.0
     t = dist.max_over_ranks(float(rank + 1))
     out_q.put((rank, lo, hi, local.numpy(), counts.numpy(), t))
     torch.distributed.destroy_process_group()
@@ -93,6 +96,8 @@ def test_single_process_helpers_are_noops():
 
     c = torch.arange(5, dtype=torch.int64)
     assert torch.equal(dist.reduce_counts(c.clone()), c)
+    red = dist.CountReducer(None)
+    assert red.mode == "single" and torch.equal(red(c.clone()), c)
     assert dist.max_over_ranks(3.5) == 3.5
     dist.barrier()
     assert dist.env_rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),

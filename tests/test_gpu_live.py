@@ -1,0 +1,270 @@
+"""GPU tests of the callers' side of the path: the live tick shim (BASELINE config 5), the process/thread
+contract of the C ABI (forked workers sharing a GPU, thread pools with per-thread contexts), the
+RCCL count reduction through the C ABI, and bench.py's own rank launcher."""
+import ctypes as C
+import json
+import os
+import queue
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import wdx_oracle as orc
+from warpdemux_amd import _lib, parallel_distances as pdist, sig_proc, synth
+from warpdemux_amd.live import LiveDemux, demux_worker
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def _ragged_rows(spec, first, n, cut=0):
+    sig, off, a_s, a_e, _ = synth.generate_packed(spec, first, n)
+    rows = [sig[off[i]:off[i + 1] - (cut * i) % 300].copy() for i in range(n)]
+    return rows
+
+
+def _oracle_tick(rows, a_s, a_e, K, refs, pad=100):
+    """per read, on the read's own (ragged) row -- the window is clamped to the row like extract_adapter does"""
+    n = len(rows)
+    p = orc.SegParams(barcode_num_events=K, padding=pad)
+    fpt = np.full((n, K), np.nan)
+    status = np.zeros(n, dtype=np.int32)
+    for i, r in enumerate(rows):
+        res = orc.fingerprint_one(r, int(a_s[i]), int(a_e[i]), p)
+        status[i] = res["status"]
+        if res["status"] == 0:
+            fpt[i] = res["fpt"]
+    ok = status == 0
+    D = np.full((n, refs.shape[0]), np.nan, dtype=np.float32)
+    D[ok] = orc.dtw_matrix(fpt[ok], refs, 15, 0.1)
+    call = np.full(n, -1, dtype=np.int32)
+    call[ok] = orc.argmin_rows(D[ok])
+    return fpt, status, D, call
+
+
+@pytest.mark.parametrize("K,nY", [(110, 6), (25, 1368)])
+def test_live_tick_matches_oracle(K, nY):
+    spec = synth.SynthSpec(n_barcodes=6)
+    refs = np.random.default_rng(2).normal(size=(nY, K))
+    ld = LiveDemux(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=K), max_reads=64, max_samples=9000)
+    try:
+        for n in (1, 5, 64, 200):   # 200 > max_reads: buffers grow
+            rows = _ragged_rows(spec, 90_000 + n, n, cut=37)
+            # the live caller's convention (worker.py:39-44): adapter_start = 0, adapter_end = polya_start
+            a_s = np.zeros(n, dtype=np.int32)
+            a_e = np.array([r.size - 150 for r in rows], dtype=np.int32)
+            if n >= 5:
+                rows[3] = np.full(1400, 80.0, dtype=np.float32)   # constant: no change-points -> failed read
+                a_e[3] = 1400
+                a_e[4] = rows[4].size + 5000     # adapter_end beyond the row: clamped like extract_adapter
+            r = ld.tick(rows, a_s, a_e, want_fpt=True)
+            fpt, status, D, call = _oracle_tick(rows, a_s, a_e, K, refs)
+            assert np.array_equal(r.status, status)
+            assert _same(r.fpt, fpt) and _same(r.dist, D) and np.array_equal(r.call, call)
+            if n >= 5:
+                assert status[3] != 0 and r.call[3] == -1
+        # success flags: a read ADAPTed rejected passes through as status 1
+        rows = _ragged_rows(spec, 91_000, 4)
+        okf = np.array([1, 0, 1, 1], dtype=np.uint8)
+        r = ld.tick(rows, np.zeros(4, np.int32), np.array([x.size for x in rows], np.int32), success=okf)
+        assert r.status[1] == 1 and (r.status[[0, 2, 3]] == 0).all()
+    finally:
+        ld.close()
+
+
+def _svm_model(k=5, n_train=300, L=25, seed=3):
+    from sklearn.svm import SVC
+
+    from warpdemux_amd.models import DTW_SVM
+
+    rng = np.random.default_rng(seed)
+    centers = rng.normal(size=(k, L))
+    y = rng.integers(0, k, n_train)
+    Xtr = centers[y] + 0.6 * rng.normal(size=(n_train, L))
+    Ktr = np.exp(-orc.dtw_matrix(Xtr, Xtr, 15, 0.1).astype(np.float64))
+    svc = SVC(kernel="precomputed", probability=True, random_state=0).fit(Ktr, y)
+    sp = orc.svm_params(svc)
+    thr = np.full(k, 0.2)
+    return DTW_SVM(Xtr, *sp[:6], {i: i + 1 for i in range(k)}, thr, 15, 0.1, block_size=500), svc
+
+
+def test_live_tick_with_model_and_queue_worker():
+    """classification_worker's outputs (worker.py:117-127): y_prob row, is_outlier = (y_pred == -1)."""
+    model, svc = _svm_model()
+    spec = synth.SynthSpec(n_barcodes=4)
+    ld = LiveDemux(model=model, max_reads=32, max_samples=9000)
+    try:
+        n = 24
+        rows = _ragged_rows(spec, 95_000, n)
+        a_e = np.array([r.size - 100 for r in rows], dtype=np.int32)
+        r = ld.tick(rows, np.zeros(n, np.int32), a_e, want_fpt=True)
+        good = r.status == 0
+        assert good.sum() >= n - 2
+        y_pred, y_prob = model.predict(r.fpt[good], nproc=1)     # the offline entry point on the same fingerprints
+        assert np.allclose(r.prob[good], y_prob, atol=1e-12) and np.array_equal(r.pred[good], y_pred)
+        Kq = np.exp(-orc.dtw_matrix(r.fpt[good], model._X, 15, 0.1))
+        assert np.abs(r.prob[good] - svc.predict_proba(Kq)).max() <= 1e-5
+
+        class ReadObject:   # the fields of live_balancing/utils.py's ReadObject the two workers touch
+            def __init__(self, data_arr, polya_start):
+                self.data_arr, self.polya_start, self.time_per_step, self.is_outlier = data_arr, polya_start, [0.01], None
+
+        qin, qout = queue.Queue(), queue.Queue()
+        for i in range(n):
+            qin.put(ReadObject(rows[i], int(a_e[i])))
+        qin.put(None)
+        t = threading.Thread(target=demux_worker, args=(qin, qout, ld))
+        t.start()
+        got = []
+        while True:
+            o = qout.get(timeout=60)
+            if o is None:
+                break
+            got.append(o)
+        t.join(10)
+        assert len(got) == int(good.sum())
+        for o, pr, pd_ in zip(got, r.prob[good], r.pred[good]):
+            assert o.data_arr.shape == (1, model.n_classes) and np.array_equal(o.data_arr[0], pr)
+            assert o.is_outlier == (pd_ == -1) and len(o.time_per_step) == 3
+    finally:
+        ld.close()
+
+
+def test_threads_with_their_own_contexts_run_concurrently():
+    """live_balancing/session.py:162-169 runs pools of worker threads; ctypes drops the GIL, so the entry points
+    really do run concurrently.  One context per thread: every thread's results must still match the oracle."""
+    spec = synth.SynthSpec(n_barcodes=6)
+    refs = np.random.default_rng(8).normal(size=(6, 110))
+    errors, done = [], []
+    start = threading.Barrier(4)
+
+    def run(tid):
+        try:
+            ld = LiveDemux(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=110), max_reads=48, max_samples=9000)
+            start.wait(timeout=120)
+            for rep in range(6):
+                n = 8 + 8 * ((tid + rep) % 5)
+                rows = _ragged_rows(spec, 10_000 * tid + 50 * rep, n)
+                a_e = np.array([r.size - 100 for r in rows], dtype=np.int32)
+                r = ld.tick(rows, np.zeros(n, np.int32), a_e, want_fpt=True)
+                fpt, status, D, call = _oracle_tick(rows, np.zeros(n, np.int32), a_e, 110, refs)
+                if not (np.array_equal(r.status, status) and _same(r.fpt, fpt) and _same(r.dist, D)
+                        and np.array_equal(r.call, call)):
+                    errors.append((tid, rep))
+                # and the per-thread default context of the module-level API
+                mb, a_s2, a_e2, _ = synth.generate_minibatch(spec, 777 * tid + rep, 16, 9000)
+                fb = sig_proc.fingerprint_batch(mb, a_s2, a_e2, sig_proc.SegParams(barcode_num_events=110))
+                of = orc.fingerprint_batch(mb, a_s2, a_e2, orc.SegParams(barcode_num_events=110))
+                if not (np.array_equal(fb.status, of[3]) and _same(fb.fpt[of[3] == 0], of[0][of[3] == 0])):
+                    errors.append((tid, rep, "module api"))
+            ld.close()
+            done.append(tid)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errors, errors
+    assert sorted(done) == [0, 1, 2, 3]
+
+
+def test_one_context_shared_by_threads_serialises():
+    """A context may also be shared: entry points serialise on it (include/wdx.h, Threading)."""
+    ctx = _lib.Context(0)
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    Y = rng.normal(size=(10, 25))
+    Xs = [rng.normal(size=(50 + 10 * i, 25)) for i in range(4)]
+    outs = [None] * 4
+
+    def run(i):
+        out = np.empty((Xs[i].shape[0], 10), dtype=np.float32)
+        for _ in range(20):
+            _lib.check(L.wdx_dtw_matrix(ctx.handle, _lib.ptr(Xs[i]), Xs[i].shape[0], _lib.ptr(Y), 10, 25, 15, 0.1,
+                                        _lib.ptr(out), None))
+        outs[i] = out
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    for i in range(4):
+        assert _same(outs[i], orc.dtw_matrix(Xs[i], Y, 15, 0.1))
+    ctx.close()
+
+
+def test_forked_workers_create_their_own_contexts():
+    """file_proc.py:1197-1243: workers are forked from a parent that imported the engine; each creates its context
+    after the fork and they share the one GPU."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "fork_workers.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(rec["pids"]) >= 2 and rec["parent"] not in rec["pids"]
+    assert all(all(w) for w in rec["ok"]), rec
+
+
+def test_context_leaves_the_callers_device_alone_and_rejects_use_after_fork_pid():
+    import torch
+
+    torch.cuda.set_device(0)
+    ctx = _lib.Context(0)
+    assert torch.cuda.current_device() == 0
+    ctx.pid += 1     # pretend this object crossed a fork
+    with pytest.raises(_lib.WdxError, match="another process"):
+        ctx.handle
+    ctx.pid -= 1
+    ctx.close()
+
+
+def test_rccl_count_reduction_through_the_c_abi():
+    """wdx_comm_unique_id / wdx_comm_init / wdx_reduce_counts with a one-rank communicator on the one GPU here
+    (the N>1 exchange is the same call; the driver's scaling run exercises it).  librccl is dlopen'ed."""
+    import torch
+
+    L = _lib.load()
+    ctx = _lib.Context(0)
+    ident = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    _lib.check(L.wdx_comm_unique_id(ident))
+    assert any(ident.raw)
+    counts = torch.arange(11, dtype=torch.int64, device="cuda") * 1000003
+    # no communicator: a no-op that succeeds
+    _lib.check(L.wdx_reduce_counts(ctx.handle, C.c_void_p(counts.data_ptr()), 11, None))
+    _lib.check(L.wdx_comm_init(ctx.handle, ident, 0, 1))
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.wdx_reduce_counts(ctx.handle, C.c_void_p(counts.data_ptr()), 11, C.c_void_p(s)))
+    torch.cuda.synchronize()
+    assert torch.equal(counts.cpu(), torch.arange(11, dtype=torch.int64) * 1000003)
+    h = np.arange(11, dtype=np.int64) * 7
+    _lib.check(L.wdx_reduce_counts_host(ctx.handle, _lib.ptr(h), 11))
+    assert np.array_equal(h, np.arange(11) * 7)
+    with pytest.raises(ValueError):
+        _lib.check(L.wdx_comm_init(ctx.handle, ident, 3, 2))
+    _lib.check(L.wdx_comm_destroy(ctx.handle))
+    ctx.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (children before any
+    GPU call).  On a 1-GPU box the two ranks share the device over gloo (WDX_BENCH_BACKEND=gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WDX_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reads", "150000"], capture_output=True, text=True, timeout=850, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["reads_total"] == 300000 and rec["config"]["workload"].startswith("C4")
+    assert rec["value"] > 0 and rec["scaling"] == "weak"

@@ -19,6 +19,20 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5  # north-star tolerance on the float distances
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _exact_path(device=None):
+    """Fingerprint on the exact general kernel only (diagnostic context option; the product path leaves it off)."""
+    ctx = _lib.default_context(device)
+    ctx.set_option(_lib.OPT_EXACT_PATH, 1)
+    try:
+        yield
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_PATH, 0)
+
+
 def _same(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
@@ -159,7 +173,9 @@ def _params_from(g, k):
     kw = dict(padding=pad, sig_norm=inv[sig_norm], outlier_thresh=float(g[f"thresh_{k}"]),
               min_obs_per_base=d, running_stat_width=w, num_events=E, accept_less_cpts=bool(acc),
               seg_norm=inv[seg_norm], barcode_num_events=K)
-    return sig_proc.SegParams(**kw), orc.SegParams(**kw)
+    c64 = bool(int(g[f"clip64_{k}"]))   # fixture made with the NumPy-1.x evaluation of the clip bounds
+    return (sig_proc.SegParams(clip_bounds="float64" if c64 else "float32", **kw),
+            orc.SegParams(clip_bounds_f64=c64, **kw))
 
 
 def test_fingerprint_golden_vectors(golden_dir):
@@ -215,7 +231,7 @@ def test_fingerprint_minibatch_vs_oracle(K):
 
 
 def test_fast_and_slow_paths_agree(monkeypatch):
-    """The 256-thread fast kernel and the exact slow path (forced with WDX_FORCE_SLOW) must give
+    """The 256-thread fast kernel and the exact slow path (forced with the WDX_OPT_EXACT_PATH context option) must give
     identical bits, with and without the optional stats, for every segmentation normalisation."""
     spec = synth.SynthSpec(n_barcodes=10)
     mb, a_s, a_e, _ = synth.generate_minibatch(spec, 77_000, 1200, 9000)
@@ -228,11 +244,9 @@ def test_fast_and_slow_paths_agree(monkeypatch):
         for K in (25, 110):
             ph = sig_proc.SegParams(barcode_num_events=K, seg_norm=seg_norm)
             po = orc.SegParams(barcode_num_events=K, seg_norm=seg_norm)
-            monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
             fast = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
-            monkeypatch.setenv("WDX_FORCE_SLOW", "1")
-            slow = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
-            monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+            with _exact_path():
+                slow = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
             assert np.array_equal(fast.status, slow.status)
             assert _same(fast.fpt, slow.fpt) and _same(fast.dwell, slow.dwell) and _same(fast.stats, slow.stats)
             fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
@@ -357,12 +371,65 @@ def test_detect_results_to_fpt_shim():
     assert res[0].adapter_event_mean == o["stats"][2]
     one = sig_proc.detect_results_to_fpt(mb[1], spc, drs[1])
     assert _same(one.barcode_fpt, res[1].barcode_fpt)
-    with pytest.raises(NotImplementedError):
-        spc.sig_extract.normalization = "mean"
-        sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+    spc.sig_extract.normalization = "mean"    # A2 "mean": float32 np.mean / np.std on the clipped signal
+    resm = sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+    om = orc.fingerprint_one(mb[0], a_s[0], a_e[0], orc.SegParams(sig_norm="mean"))
+    assert resm[0].success and _same(resm[0].barcode_fpt, om["fpt"]) and not _same(om["fpt"], o["fpt"])
     with pytest.raises(ValueError):
         spc.sig_extract.normalization = "bogus"
         sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+
+
+def test_signal_normalisation_mean_matches_oracle():
+    """sig_extract.normalization = "mean" (sig_proc.py:99-111 on the float32 adapter signal): NumPy's float32
+    pairwise sums incl. the 8192-element chunking of add.reduce (windows longer than 8192 samples), and the
+    nanmean / nanstd branch for windows that hold NaNs.  The golden G4 cases pin the oracle to the reference;
+    here the engine is compared with the oracle on many more shapes."""
+    rng = np.random.default_rng(12)
+    lens = [700, 1320, 2048, 4097, 4801, 6000, 8191, 8192, 8193, 8200, 9973, 11000, 11200, 5000, 5000, 300]
+    n, stride = len(lens), 11200
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, ln in enumerate(lens):
+        ev = rng.integers(20, 60)
+        lvl = np.repeat(rng.normal(80, 15, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = (lvl + rng.normal(0, 2, ln)).astype(np.float32)
+    mb[13, 1000:1003] = np.nan          # NaNs inside the window -> nanmean / nanstd
+    mb[14, 4990:5000] = np.nan
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array(lens, dtype=np.int32)
+    for K, thr in ((25, 5.0), (110, 3.0)):
+        kw = dict(padding=0, sig_norm="mean", barcode_num_events=K, outlier_thresh=thr)
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+        assert np.array_equal(fb.status, status)
+        good = status == 0
+        assert good.sum() >= 12
+        assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good])
+
+
+def test_clip_bound_rules_float32_and_float64():
+    """The clip bounds under NumPy >= 2 (float32) and under NumPy 1.x / np.float64 thresholds (float64, rounded
+    once): both rules through the engine, each against the oracle; with a threshold like 2.7 they differ."""
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 31_000, 300, 9000)
+    differ = 0
+    for thr in (2.7, 3.3, 5.0):
+        out = {}
+        for rule in ("float32", "float64"):
+            fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=110, outlier_thresh=thr,
+                                                                             clip_bounds=rule))
+            fpt, dwell, stats, status = orc.fingerprint_batch(
+                mb, a_s, a_e, orc.SegParams(barcode_num_events=110, outlier_thresh=thr, clip_bounds_f64=rule == "float64"))
+            good = status == 0
+            assert np.array_equal(fb.status, status) and good.sum() > 290
+            assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good])
+            out[rule] = fb.fpt
+        differ += int(not _same(out["float32"], out["float64"]))
+    assert differ >= 1
+    # "auto" follows the NumPy of this process; an np.float64 threshold always means float64 bounds
+    auto = sig_proc.SegParams(outlier_thresh=2.7).to_c()
+    assert auto.clip_bounds_f64 == int(int(np.__version__.split(".")[0]) < 2)
+    assert sig_proc.SegParams(outlier_thresh=np.float64(2.7)).to_c().clip_bounds_f64 == 1
 
 
 # ------------------------------------------------------------------------ fused device pipeline ----
@@ -622,11 +689,9 @@ def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch)
     for K, seg_norm in ((25, "mean"), (110, "median")):
         ph = sig_proc.SegParams(padding=0, barcode_num_events=K, seg_norm=seg_norm)
         po = orc.SegParams(padding=0, barcode_num_events=K, seg_norm=seg_norm)
-        monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
         fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
-        monkeypatch.setenv("WDX_FORCE_SLOW", "1")
-        sl = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
-        monkeypatch.delenv("WDX_FORCE_SLOW", raising=False)
+        with _exact_path():
+            sl = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
         fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
         assert np.array_equal(fb.status, status) and np.array_equal(sl.status, status) and (status == 0).all()
         assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats)

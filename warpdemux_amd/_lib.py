@@ -22,15 +22,21 @@ WDX_ERR_HIP = -3
 WDX_ERR_UNSUPPORTED = -4
 WDX_ERR_NO_REFS = -5
 
-K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT = 0, 1, 2, 3
+K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE = 0, 1, 2, 3, 4, 5
+
+# wdx_ctx_set_option selectors (diagnostics; the product path leaves all of them 0)
+OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBUG_OCCUPANCY, OPT_FAST_PEAK_CAP = 1, 2, 3, 4, 5, 6
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
 
 NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 
 # every symbol include/wdx.h declares (tests check the .so exports each of them)
 EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
-    "wdx_ctx_synchronize", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_svm_set_model",
+    "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_unique_id", "wdx_comm_init",
+    "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
+    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
@@ -50,6 +56,8 @@ class SegParamsC(C.Structure):
         ("accept_less_cpts", C.c_int32),
         ("seg_norm", C.c_int32),
         ("barcode_num_events", C.c_int32),
+        ("clip_bounds_f64", C.c_int32),
+        ("outlier_thresh_f64", C.c_double),
     ]
 
 
@@ -133,6 +141,20 @@ def load():
         L.wdx_ctx_destroy.argtypes = [vp]
         L.wdx_ctx_synchronize.restype = C.c_int
         L.wdx_ctx_synchronize.argtypes = [vp, vp]
+        L.wdx_ctx_stream.restype = C.c_int
+        L.wdx_ctx_stream.argtypes = [vp, P(vp)]
+        L.wdx_ctx_set_option.restype = C.c_int
+        L.wdx_ctx_set_option.argtypes = [vp, i32, i64]
+        L.wdx_comm_unique_id.restype = C.c_int
+        L.wdx_comm_unique_id.argtypes = [vp]
+        L.wdx_comm_init.restype = C.c_int
+        L.wdx_comm_init.argtypes = [vp, vp, i32, i32]
+        L.wdx_comm_destroy.restype = C.c_int
+        L.wdx_comm_destroy.argtypes = [vp]
+        L.wdx_reduce_counts.restype = C.c_int
+        L.wdx_reduce_counts.argtypes = [vp, vp, i32, vp]
+        L.wdx_reduce_counts_host.restype = C.c_int
+        L.wdx_reduce_counts_host.argtypes = [vp, vp, i32]
         L.wdx_dtw_matrix.restype = C.c_int
         L.wdx_dtw_matrix.argtypes = [vp, vp, i64, vp, i64, i64, i32, f64, vp, vp]
         L.wdx_refs_generation.restype = C.c_int
@@ -150,7 +172,9 @@ def load():
         L.wdx_dtw_svm_predict.restype = C.c_int
         L.wdx_dtw_svm_predict.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_demux_batch.restype = C.c_int
-        L.wdx_demux_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
+        L.wdx_demux_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), i64, vp, vp, vp, vp]
+        L.wdx_live_tick.restype = C.c_int
+        L.wdx_live_tick.argtypes = [vp, vp, vp, i64, vp, vp, vp, P(SegParamsC), i64, i32, vp, vp, vp, vp, vp, vp, vp]
         L.wdx_fingerprint_dev.restype = C.c_int
         L.wdx_fingerprint_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp]
         L.wdx_demux_workspace_bytes.restype = i64
@@ -171,7 +195,7 @@ def load():
         L.wdx_synth_lengths_dev.argtypes = [vp, u64, i64, i64, i32, vp, vp, vp]
         L.wdx_synth_fill_dev.restype = C.c_int
         L.wdx_synth_fill_dev.argtypes = [vp, u64, i64, i64, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp]
-        if L.wdx_abi_version() != 1:
+        if L.wdx_abi_version() != ABI_VERSION:
             raise WdxError("libwdx_hip.so ABI version mismatch")
         _lib = L
         return L
@@ -213,7 +237,16 @@ class Context:
     def handle(self):
         if self._h is None:
             raise WdxError("context destroyed")
+        if self.pid != os.getpid():
+            raise WdxError("this context was created in another process (fork): create one per process")
         return self._h
+
+    def set_option(self, option: int, value: int = 1):
+        """Diagnostic switch (wdx_ctx_set_option); tests and profiling tools only."""
+        check(self._L.wdx_ctx_set_option(self.handle, int(option), int(value)))
+
+    def synchronize(self, stream=None):
+        check(self._L.wdx_ctx_synchronize(self.handle, stream))
 
     def close(self):
         if self._h is not None and self.pid == os.getpid():

@@ -1,13 +1,12 @@
 // C ABI of libwdx_hip.so (include/wdx.h): context, workspaces, host<->device plumbing.
 // The arithmetic lives in wdx_dtw.hip / wdx_fingerprint.hip; nothing here computes results.
-#include "wdx_common.h"
+#include "wdx_ctx.h"
 
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
-#include <mutex>
-#include <vector>
+#include <algorithm>
 
 namespace wdx {
 
@@ -37,99 +36,113 @@ static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce48422232
     return h;
 }
 
-struct Buffer {  // grow-only device workspace
-    void *p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return WDX_SUCCESS;
-        if (p) (void)hipFree(p);
+int Buffer::ensure(size_t need) {
+    if (need <= bytes) return WDX_SUCCESS;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    size_t want = need + need / 4;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(&p, need);
+        want = need;
+    }
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
         p = nullptr;
-        bytes = 0;
-        size_t want = need + need / 4;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            e = hipMalloc(&p, need);
-            want = need;
-        }
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-            p = nullptr;
-            return WDX_ERR_HIP;
-        }
-        bytes = want;
-        return WDX_SUCCESS;
+        return WDX_ERR_HIP;
     }
-    void release() {
-        if (p) (void)hipFree(p);
+    bytes = want;
+    return WDX_SUCCESS;
+}
+
+void Buffer::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+int PinnedBuffer::ensure(size_t need) {
+    if (need <= bytes) return WDX_SUCCESS;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+    const size_t want = need + need / 4;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         p = nullptr;
-        bytes = 0;
+        return WDX_ERR_HIP;
     }
-};
+    bytes = want;
+    return WDX_SUCCESS;
+}
 
-constexpr int kNumTimed = 5;
+void PinnedBuffer::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    bytes = 0;
+}
 
-}  // namespace wdx
-
-using namespace wdx;
-
-struct wdx_ctx {
-    int device = 0;
-    std::mutex mu;
-    DtwRefs refs;
-    Buffer refs_pad, refs_T, refs_nan;
-    // host-buffer call workspaces
-    Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws, svm_buf;
-    int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes
-    SvmDev svm{};
-    bool svm_set = false;
-    // timing
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[kNumTimed];
-    std::vector<int64_t> pending_launches[kNumTimed];
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    double acc_ms[kNumTimed] = {};
-    int64_t launches[kNumTimed] = {};
-};
-
-namespace {
-
-struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
-    wdx_ctx *c;
-    int id;
-    hipStream_t s;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    int64_t n_launches = 0;  // kernel launches bracketed by this event pair (0 -> counted as 1)
-    Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
-        if (!c->timing) return;
-        if (!c->pool.empty()) {
-            ev = c->pool.back();
-            c->pool.pop_back();
-        } else {
-            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
-                ev = {nullptr, nullptr};
-                return;
-            }
+DeviceGuard::DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+            rc = WDX_ERR_HIP;
+            prev = -1;
         }
-        (void)hipEventRecord(ev.first, s);
+    } else {
+        prev = -1;  // nothing to restore
     }
-    ~Timed() {
-        if (!ev.first) return;
-        (void)hipEventRecord(ev.second, s);
-        c->pending[id].push_back(ev);
-        c->pending_launches[id].push_back(n_launches > 0 ? n_launches : 1);
+}
+
+DeviceGuard::~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+Timed::Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
+    if (!c->timing) return;
+    if (!c->pool.empty()) {
+        ev = c->pool.back();
+        c->pool.pop_back();
+    } else {
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+            ev = {nullptr, nullptr};
+            return;
+        }
     }
-};
+    (void)hipEventRecord(ev.first, s);
+}
+
+Timed::~Timed() {
+    if (!ev.first) return;
+    (void)hipEventRecord(ev.second, s);
+    c->pending[id].push_back(ev);
+    c->pending_launches[id].push_back(n_launches > 0 ? n_launches : 1);
+}
 
 int check_ctx(wdx_ctx *ctx) {
     if (!ctx) {
         set_error("null context");
         return WDX_ERR_INVALID;
     }
-    WDX_HIP_TRY(hipSetDevice(ctx->device));
     return WDX_SUCCESS;
 }
 
-int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+int use_stream(wdx_ctx *ctx, hipStream_t s) {
+    if (ctx->last_stream_valid && ctx->last_stream != s) WDX_HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    ctx->last_stream = s;
+    ctx->last_stream_valid = true;
+    return WDX_SUCCESS;
+}
+
+}  // namespace wdx
+
+using namespace wdx;
+
+namespace wdx {
 
 // (re)build the resident reference set from a HOST array
 int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
@@ -154,6 +167,10 @@ int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_
         return WDX_SUCCESS;
     }
     ++ctx->refs_gen;
+    // not set until every buffer below is rebuilt: a failure in the middle must not leave a stale hash over
+    // freed or half-written buffers (a later call then reports WDX_ERR_NO_REFS instead of reading them)
+    R.window = 0;
+    R.content_hash = 0;
     const int halo = kMaxRegWindow - 1;
     const int64_t Lpad = L + 2 * halo;
     const int64_t ldT = round_up(nY > 0 ? nY : 1, 64);
@@ -203,7 +220,7 @@ int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int
     if (sb && (rc = ctx->scratch.ensure((size_t)sb))) return rc;
     // small problems: one launch of the anti-diagonal wavefront kernel straight from the row-major
     // inputs (no transpose), then the argmin
-    if (dtw_wavefront_eligible(nX, R.nY, L, R.window)) {
+    if (dtw_wavefront_eligible(nX, R.nY, L, R.window, ctx->knobs)) {
         {
             Timed t(ctx, WDX_K_DTW, stream);
             if ((rc = launch_dtw_wavefront(dX, nX, R.pad, R.Lpad, R.halo, R.nY, L, R.window, R.penalty,
@@ -230,13 +247,13 @@ int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int
             if ((rc = launch_dtw((const double *)ctx->tmp1.p, ld, nX, (const uint8_t *)ctx->tmp2.p,
                                  R.pad, R.Lpad, R.halo, R.nY, R.has_nan, L, R.window, R.penalty,
                                  d_out, R.nY, 1, nullptr, ctx->scratch.p, (int64_t)ctx->scratch.bytes,
-                                 stream)))
+                                 stream, ctx->knobs)))
                 return rc;
             return launch_argmin(d_out, nX, R.nY, d_argmin, stream);
         }
         return launch_dtw((const double *)ctx->tmp1.p, ld, nX, (const uint8_t *)ctx->tmp2.p, R.pad,
                           R.Lpad, R.halo, R.nY, R.has_nan, L, R.window, R.penalty, d_out, R.nY, 1,
-                          d_argmin, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream);
+                          d_argmin, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream, ctx->knobs);
     }
     // few reads, many refs (live / per-read calls): lanes = refs, the read is the uniform operand
     const int halo = kMaxRegWindow - 1;
@@ -253,14 +270,14 @@ int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int
         Timed t(ctx, WDX_K_DTW, stream);
         if ((rc = launch_dtw(R.T, R.ldT, R.nY, R.has_nan, (const double *)ctx->tmp1.p, Lpad, halo,
                              nX, (const uint8_t *)ctx->tmp2.p, L, R.window, R.penalty, d_out, 1,
-                             R.nY, nullptr, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream)))
+                             R.nY, nullptr, ctx->scratch.p, (int64_t)ctx->scratch.bytes, stream, ctx->knobs)))
             return rc;
     }
     if (d_argmin) return launch_argmin(d_out, nX, R.nY, d_argmin, stream);
     return WDX_SUCCESS;
 }
 
-}  // namespace
+}  // namespace wdx
 
 extern "C" {
 
@@ -294,7 +311,8 @@ int wdx_ctx_create(int device, wdx_ctx **out) {
         set_error("device %d out of range (0..%d)", device, n - 1);
         return WDX_ERR_INVALID;
     }
-    WDX_HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (guard.rc) return guard.rc;
     hipDeviceProp_t prop;
     WDX_HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -304,18 +322,30 @@ int wdx_ctx_create(int device, wdx_ctx **out) {
     }
     wdx_ctx *c = new wdx_ctx();
     c->device = device;
+    // the context's own stream: host-buffer calls of different contexts (one per thread)
+    // overlap instead of queueing on the NULL stream
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        delete c;
+        return WDX_ERR_HIP;
+    }
     *out = c;
     return WDX_SUCCESS;
 }
 
 void wdx_ctx_destroy(wdx_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
+    comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf})
         b->release();
+    ctx->pin_in.release();
+    ctx->pin_out.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int k = 0; k < kNumTimed; ++k)
         for (auto &e : ctx->pending[k]) {
             (void)hipEventDestroy(e.first);
@@ -328,16 +358,42 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     delete ctx;
 }
 
+int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
+    WDX_ENTER(ctx);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    switch (option) {
+        case WDX_OPT_EXACT_PATH: ctx->knobs.exact_path = value != 0; break;
+        case WDX_OPT_NO_WAVEFRONT_DTW: ctx->knobs.no_wavefront = value != 0; break;
+        case WDX_OPT_NO_SHORT_DTW: ctx->knobs.no_short_dtw = value != 0; break;
+        case WDX_OPT_SVM_SCALAR: ctx->knobs.svm_scalar = value != 0; break;
+        case WDX_OPT_DEBUG_OCCUPANCY: ctx->knobs.debug_occ = value != 0; break;
+        case WDX_OPT_FAST_PEAK_CAP: ctx->knobs.fast_peak_cap = (int)value; break;
+        default:
+            set_error("unknown option %d", (int)option);
+            return WDX_ERR_INVALID;
+    }
+    return WDX_SUCCESS;
+}
+
+int wdx_ctx_stream(wdx_ctx *ctx, void **stream) {
+    WDX_ENTER(ctx);
+    if (!stream) {
+        set_error("ctx_stream: null output");
+        return WDX_ERR_INVALID;
+    }
+    *stream = (void *)ctx->stream;
+    return WDX_SUCCESS;
+}
+
 int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
-    WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    WDX_ENTER(ctx);
+    // NULL = the context's own stream (the one every host-buffer call runs on)
+    WDX_HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return WDX_SUCCESS;
 }
 
 int wdx_refs_generation(wdx_ctx *ctx, int64_t *generation) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (!generation) {
         set_error("refs_generation: null output");
         return WDX_ERR_INVALID;
@@ -349,35 +405,35 @@ int wdx_refs_generation(wdx_ctx *ctx, int64_t *generation) {
 
 int wdx_set_refs(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window,
                  double penalty) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
-    return set_refs_locked(ctx, Y, nY, L, window, penalty, nullptr);
+    if ((rc = use_stream(ctx, ctx->stream))) return rc;
+    return set_refs_locked(ctx, Y, nY, L, window, penalty, ctx->stream);
 }
 
 int wdx_dtw_matrix_dev(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int32_t *d_argmin,
                        void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (nX < 0 || (nX > 0 && (!dX || !d_out))) {
         set_error("dtw_matrix_dev: bad arguments");
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    if ((rc = use_stream(ctx, (hipStream_t)stream))) return rc;
     return dtw_dev_locked(ctx, dX, nX, d_out, d_argmin, (hipStream_t)stream);
 }
 
 int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, int64_t nY,
                    int64_t L, int32_t window, double penalty, float *out, int32_t *argmin) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (nX < 0 || nY < 0 || L <= 0 || (nX > 0 && !X) || (nY > 0 && !Y) ||
         (nX > 0 && nY > 0 && !out)) {
         set_error("dtw_matrix: need nX,nY >= 0, L > 0 and non-null buffers");
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
+    if ((rc = use_stream(ctx, s))) return rc;
     if ((rc = set_refs_locked(ctx, Y, nY, L, window, penalty, s))) return rc;
     if (nX == 0 || nY == 0) {
         if (argmin)
@@ -405,18 +461,18 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                         const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
                         const wdx_seg_params *p, double *d_fpt, int64_t *d_dwell, double *d_stats,
                         int32_t *d_status, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (n_reads < 0 || !p || (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status))) {
         set_error("fingerprint_dev: bad arguments");
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    if ((rc = use_stream(ctx, (hipStream_t)stream))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     Timed t(ctx, WDX_K_FINGERPRINT, (hipStream_t)stream);
     return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                               d_a_end, d_ok, *p, d_fpt, d_dwell, d_stats, d_status,
-                              (hipStream_t)stream, ctx->fp_ws.p, &t.n_launches);
+                              (hipStream_t)stream, ctx->fp_ws.p, ctx->knobs, &t.n_launches);
 }
 
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
@@ -424,17 +480,17 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
                                 const int32_t *d_a_start, const int32_t *d_a_end,
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
                                 int64_t prof_reads, int32_t fast_path, int32_t stop_phase, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (!p || !d_prof || !d_status) {
         set_error("fingerprint_profile_dev: bad arguments");
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
+    if ((rc = use_stream(ctx, (hipStream_t)stream))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     rc = launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
                             nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
-                            fast_path ? ctx->fp_ws.p : nullptr, nullptr, d_prof, prof_reads, stop_phase);
+                            fast_path ? ctx->fp_ws.p : nullptr, ctx->knobs, nullptr, d_prof, prof_reads, stop_phase);
     if (rc == WDX_SUCCESS && fast_path && prof_reads > 0 && stop_phase == 0) {
         // slot 15 of read 0 <- number of reads the fast kernel handed to the slow path
         WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -450,8 +506,7 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
                           const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
                           const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
                           int32_t *status) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (n_reads < 0 || stride < 0 || !p ||
         (n_reads > 0 && (!sig || !a_start || !a_end || !fpt || !dwell || !stats || !status))) {
         set_error("fingerprint_batch: bad arguments");
@@ -459,7 +514,8 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
     }
     if (n_reads == 0) return WDX_SUCCESS;
     std::lock_guard<std::mutex> g(ctx->mu);
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
+    if ((rc = use_stream(ctx, s))) return rc;
     const int64_t K = p->barcode_num_events;
     if (K < 1) {
         set_error("barcode_num_events must be >= 1");
@@ -505,7 +561,7 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p,
                                      (double *)ctx->out0.p, (int64_t *)ctx->out1.p,
                                      (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p,
-                                     &t.n_launches)))
+                                     ctx->knobs, &t.n_launches)))
             return rc;
     }
     WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
@@ -529,8 +585,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                   const wdx_seg_params *p, double *d_fpt, int64_t *d_dwell, double *d_stats,
                   int32_t *d_status, float *d_dist, int32_t *d_call, int64_t *d_counts, void *d_work,
                   void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (n_reads < 0 || !p ||
         (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status || !d_dist || !d_call || !d_work))) {
         set_error("demux_dev: bad arguments");
@@ -554,6 +609,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
     }
     if (n_reads == 0) return WDX_SUCCESS;
     hipStream_t s = (hipStream_t)stream;
+    if ((rc = use_stream(ctx, s))) return rc;
     const int64_t ld = round_up(n_reads, 64);
     unsigned char *w = (unsigned char *)d_work;
     double *fpt = d_fpt ? d_fpt : (double *)w;
@@ -564,7 +620,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
         Timed t(ctx, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                                      d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s, fp_ws,
-                                     &t.n_launches)))
+                                     ctx->knobs, &t.n_launches)))
             return rc;
     }
     {
@@ -574,7 +630,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
     {
         Timed t(ctx, WDX_K_DTW, s);
         if ((rc = launch_dtw(fptT, ld, n_reads, flags, R.pad, R.Lpad, R.halo, R.nY, R.has_nan, R.L,
-                             R.window, R.penalty, d_dist, R.nY, 1, d_call, nullptr, 0, s)))
+                             R.window, R.penalty, d_dist, R.nY, 1, d_call, nullptr, 0, s, ctx->knobs)))
             return rc;
     }
     Timed t(ctx, WDX_K_COUNT, s);
@@ -583,9 +639,9 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
 
 int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
                     const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
-                    const wdx_seg_params *p, double *fpt, float *dist, int32_t *call, int32_t *status) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+                    const wdx_seg_params *p, int64_t n_refs, double *fpt, float *dist, int32_t *call,
+                    int32_t *status) {
+    WDX_ENTER(ctx);
     if (n_reads < 0 || stride < 0 || !p || (n_reads > 0 && (!sig || !a_start || !a_end || !call || !status))) {
         set_error("demux_batch: bad arguments");
         return WDX_ERR_INVALID;
@@ -602,7 +658,13 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
         set_error("barcode_num_events (%lld) != reference length (%lld)", (long long)K, (long long)R.L);
         return WDX_ERR_INVALID;
     }
-    hipStream_t s = nullptr;
+    if (n_refs != R.nY) {
+        set_error("demux_batch: the caller sized `dist` for %lld references but %lld are resident",
+                  (long long)n_refs, (long long)R.nY);
+        return WDX_ERR_INVALID;
+    }
+    hipStream_t s = ctx->stream;
+    if ((rc = use_stream(ctx, s))) return rc;
     int64_t max_len = 0, col0 = stride, col1 = 0;  // columns [col0, col1) hold every adapter window of the batch
     for (int64_t r = 0; r < n_reads; ++r) {
         if (ok && !ok[r]) continue;
@@ -640,7 +702,7 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
         if ((rc = launch_fingerprint((const float *)ctx->in0.p, nullptr, nullptr, stride, max_len, n_reads,
                                      (const int32_t *)ctx->in1.p, (const int32_t *)ctx->in2.p,
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p, (double *)ctx->out0.p,
-                                     nullptr, nullptr, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p, &t.n_launches)))
+                                     nullptr, nullptr, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p, ctx->knobs, &t.n_launches)))
             return rc;
     }
     if (R.nY > 0) {
@@ -662,8 +724,7 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
 }
 
 int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (!m || m->n_classes < 2 || m->n_classes > 16 || m->n_sv < 1 || m->n_train < 1 || !m->n_support ||
         !m->support || !m->dual_coef || !m->rho || !m->probA || !m->probB || m->pwr_dist < 1) {
         set_error("svm_set_model: need 2..16 classes, support vectors, coefficients and Platt parameters");
@@ -690,9 +751,12 @@ int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {
             return WDX_ERR_INVALID;
         }
     std::lock_guard<std::mutex> g(ctx->mu);
+    if ((rc = use_stream(ctx, ctx->stream))) return rc;
+    WDX_HIP_TRY(hipStreamSynchronize(ctx->stream));  // no kernel may still be reading the previous model
     // one device block: [doubles: dual_coef | rho | probA | probB | thresholds][int32: n_support | start | support | label_map]
     const size_t nd = (size_t)(k - 1) * nsv + 3 * (size_t)np + (size_t)k;
     const size_t ni = 3 * (size_t)k + (size_t)nsv;
+    ctx->svm_set = false;  // not set until the upload below has succeeded
     if ((rc = ctx->svm_buf.ensure(nd * 8 + ni * 4))) return rc;
     std::vector<unsigned char> h(nd * 8 + ni * 4);
     double *hd = reinterpret_cast<double *>(h.data());
@@ -731,8 +795,7 @@ int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {
 
 int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                         double *d_conf, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     if (!ctx->svm_set) {
         set_error("no SVM model: call wdx_svm_set_model first");
@@ -742,13 +805,13 @@ int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_
         set_error("svm_predict_dev: bad arguments");
         return WDX_ERR_INVALID;
     }
+    if ((rc = use_stream(ctx, (hipStream_t)stream))) return rc;
     Timed t(ctx, WDX_K_SVM, (hipStream_t)stream);
-    return launch_svm_predict(ctx->svm, d_dist, n, d_prob, d_pred, d_conf, (hipStream_t)stream);
+    return launch_svm_predict(ctx->svm, d_dist, n, d_prob, d_pred, d_conf, (hipStream_t)stream, ctx->knobs);
 }
 
 int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     DtwRefs &R = ctx->refs;
     if (R.window == 0 || !ctx->svm_set) {
@@ -764,7 +827,8 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
         return WDX_ERR_INVALID;
     }
     if (n == 0) return WDX_SUCCESS;
-    hipStream_t s = nullptr;
+    hipStream_t s = ctx->stream;
+    if ((rc = use_stream(ctx, s))) return rc;
     const int k = ctx->svm.k;
     // rows per pass: the (rows, nY) float32 distance block stays <= 1 GiB and never leaves HBM
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)1 << 30) / (4 * (int64_t)R.nY)));
@@ -780,7 +844,7 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
         {
             Timed t(ctx, WDX_K_SVM, s);
             if ((rc = launch_svm_predict(ctx->svm, (const float *)ctx->out0.p, m, (double *)ctx->out1.p,
-                                         (int32_t *)ctx->out2.p, (double *)ctx->out3.p, s)))
+                                         (int32_t *)ctx->out2.p, (double *)ctx->out3.p, s, ctx->knobs)))
                 return rc;
         }
         if (prob) WDX_HIP_TRY(hipMemcpyAsync(prob + r0 * k, ctx->out1.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, s));
@@ -792,16 +856,14 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
 }
 
 int wdx_kernel_timing(wdx_ctx *ctx, int enable) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->timing = enable != 0;
     return WDX_SUCCESS;
 }
 
 int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     if (kernel_id < 0 || kernel_id >= kNumTimed) {
         set_error("kernel id out of range");
         return WDX_ERR_INVALID;
@@ -824,8 +886,7 @@ int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
 }
 
 int wdx_kernel_time_reset(wdx_ctx *ctx) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     for (int k = 0; k < kNumTimed; ++k) {
         for (auto &e : ctx->pending[k]) {
@@ -841,16 +902,14 @@ int wdx_kernel_time_reset(wdx_ctx *ctx) {
 }
 
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     return launch_calib_read(d_p, n, d_out, (hipStream_t)stream);
 }
 
 int wdx_synth_lengths_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t n_reads,
                           int32_t n_barcodes, const int32_t *d_dwell_table, int64_t *d_len,
                           void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     return launch_synth_lengths(seed, first_read, n_reads, n_barcodes, d_dwell_table, d_len,
                                 (hipStream_t)stream);
 }
@@ -859,8 +918,7 @@ int wdx_synth_fill_dev(wdx_ctx *ctx, uint64_t seed, int64_t first_read, int64_t 
                        int32_t n_barcodes, int32_t n_bc_events, float noise_scale, int32_t spikes,
                        const int32_t *d_dwell_table, const float *d_lead, const float *d_bc,
                        const int64_t *d_off, float *d_sig, int32_t *d_barcode, void *stream) {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    WDX_ENTER(ctx);
     return launch_synth_fill(seed, first_read, n_reads, n_barcodes, n_bc_events, noise_scale, spikes,
                              d_dwell_table, d_lead, d_bc, d_off, d_sig, d_barcode,
                              (hipStream_t)stream);

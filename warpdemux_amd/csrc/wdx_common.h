@@ -20,6 +20,32 @@ void set_error(const char *fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Diagnostic switches of one context (wdx_ctx_set_option).  All off on the product path; nothing in the
+// library reads the environment.
+struct Knobs {
+    bool exact_path = false;    // WDX_OPT_EXACT_PATH: fingerprint every read on the exact general kernel
+    bool no_wavefront = false;  // WDX_OPT_NO_WAVEFRONT_DTW
+    bool no_short_dtw = false;  // WDX_OPT_NO_SHORT_DTW
+    bool svm_scalar = false;    // WDX_OPT_SVM_SCALAR
+    bool debug_occ = false;     // WDX_OPT_DEBUG_OCCUPANCY
+    int fast_peak_cap = 0;      // WDX_OPT_FAST_PEAK_CAP (0 = built-in capacity)
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): a launch on the live
+// path is ~0.1 ms, the attribute call must not be paid on each of them.  One static LdsAttr per kernel.
+struct LdsAttr {
+    int set[16] = {};
+    template <class K>
+    int ensure(K kern, size_t lds) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+        if (dev >= 0 && __atomic_load_n(&set[dev], __ATOMIC_RELAXED) >= (int)lds) return WDX_SUCCESS;
+        WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev >= 0) __atomic_store_n(&set[dev], (int)lds, __ATOMIC_RELAXED);
+        return WDX_SUCCESS;
+    }
+};
+
 // ---- DTW (wdx_dtw.hip) -----------------------------------------------------------------------
 // Largest Sakoe-Chiba window handled by the register-band kernel; wider / unbanded problems with
 // L > this go to the scratch-row kernel.
@@ -42,10 +68,11 @@ struct DtwRefs {  // resident reference set, both layouts (see DESIGN.md "DTW da
 int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan /*nullable*/,
                const double *Bpad, int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan,
                int64_t L, int window, double penalty, float *out, int64_t sA, int64_t sB,
-               int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream);
+               int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream,
+               const Knobs &knobs);
 int64_t dtw_scratch_bytes(int64_t L, int window);
 // anti-diagonal wavefront kernel for small problems (latency path)
-bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window);
+bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window, const Knobs &knobs);
 int launch_dtw_wavefront(const double *X, int64_t nX, const double *Ypad, int64_t Lpad, int halo,
                          int64_t nY, int64_t L, int window, double penalty, float *out,
                          hipStream_t stream);
@@ -70,7 +97,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
-                       int64_t *n_launches = nullptr, long long *d_prof = nullptr,
+                       const Knobs &knobs, int64_t *n_launches = nullptr, long long *d_prof = nullptr,
                        int64_t prof_reads = 0, int stop_phase = 0);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
 
@@ -90,7 +117,7 @@ struct SvmDev {  // device-resident SVC(kernel="precomputed", probability=True) 
     float ngamma;  // -gamma rounded to float32 (NumPy: python float * float32 array -> float32)
 };
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
-                       double *d_conf, hipStream_t stream);
+                       double *d_conf, hipStream_t stream, const Knobs &knobs);
 
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream);
 

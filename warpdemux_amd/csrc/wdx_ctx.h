@@ -1,0 +1,103 @@
+// The opaque context behind include/wdx.h's wdx_ctx (internal; shared by wdx_api.hip, wdx_comm.hip
+// and wdx_live.hip).  Nothing here computes results.
+#pragma once
+#include "wdx_common.h"
+
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace wdx {
+
+struct Buffer {  // grow-only device workspace
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+};
+
+struct PinnedBuffer {  // grow-only page-locked host staging area
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);
+    void release();
+};
+
+constexpr int kNumTimed = 6;
+
+// RAII: make the context's device current for the duration of one entry point and put the caller's
+// device back afterwards (a host thread that also drives torch must not find its device switched).
+struct DeviceGuard {
+    int prev = -1;
+    int rc = WDX_SUCCESS;
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+struct Comm;  // wdx_comm.hip: RCCL communicator + the dlopen'ed entry points
+
+}  // namespace wdx
+
+struct wdx_ctx {
+    int device = 0;
+    std::mutex mu;
+    hipStream_t stream = nullptr;  // the context's own non-blocking stream: every host-buffer call runs on it
+    hipStream_t last_stream = nullptr;  // stream of the latest enqueue that used the shared workspaces
+    bool last_stream_valid = false;
+    wdx::Knobs knobs;
+    wdx::DtwRefs refs;
+    wdx::Buffer refs_pad, refs_T, refs_nan;
+    // host-buffer call workspaces
+    wdx::Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws, svm_buf, ref_buf;
+    wdx::PinnedBuffer pin_in, pin_out;  // staging of small (live-tick sized) host-buffer calls
+    int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes
+    wdx::SvmDev svm{};
+    bool svm_set = false;
+    wdx::Comm *comm = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[wdx::kNumTimed];
+    std::vector<int64_t> pending_launches[wdx::kNumTimed];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double acc_ms[wdx::kNumTimed] = {};
+    int64_t launches[wdx::kNumTimed] = {};
+};
+
+namespace wdx {
+
+struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
+    wdx_ctx *c;
+    int id;
+    hipStream_t s;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    int64_t n_launches = 0;  // kernel launches bracketed by this event pair (0 -> counted as 1)
+    Timed(wdx_ctx *c_, int id_, hipStream_t s_);
+    ~Timed();
+};
+
+// Entry-point prologue: null check.  (The device is made current by a DeviceGuard in the caller.)
+int check_ctx(wdx_ctx *ctx);
+// The shared workspaces of a context are ordered by stream order only.  Call with the mutex held before
+// enqueueing on `s`: when the previous user enqueued on a different stream, wait for that stream first.
+int use_stream(wdx_ctx *ctx, hipStream_t s);
+void comm_destroy(wdx_ctx *ctx);
+// (wdx_api.hip) with the context's mutex held:
+// (re)build the resident reference set from a HOST array (content-hashed: uploads only on change)
+int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t window, double penalty,
+                    hipStream_t stream);
+// DTW of device rows dX (nX, L) against the resident refs -> d_out (nX, nY) [+ argmin]
+int dtw_dev_locked(wdx_ctx *ctx, const double *dX, int64_t nX, float *d_out, int32_t *d_argmin,
+                   hipStream_t stream);
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace wdx
+
+#define WDX_ENTER(ctx)                                  \
+    if (int _e = ::wdx::check_ctx(ctx)) return _e;      \
+    ::wdx::DeviceGuard _guard((ctx)->device);           \
+    if (_guard.rc) return _guard.rc;                    \
+    int rc = WDX_SUCCESS;                               \
+    (void)rc

@@ -394,15 +394,15 @@ int launch_dtw_wavefront(const double *X, int64_t nX, const double *Ypad, int64_
     return WDX_SUCCESS;
 }
 
-bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window) {
+bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window, const Knobs &knobs) {
     const int64_t w = (window <= 0 || window > L) ? L : window;
-    return w <= 16 && L >= 1 && L <= 256 && nX * nY <= 16384 && !getenv("WDX_NO_WAVEFRONT");
+    return w <= 16 && L >= 1 && L <= 256 && nX * nY <= 16384 && !knobs.no_wavefront;
 }
 
 int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, const double *Bpad,
                int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan, int64_t L, int window,
                double penalty, float *out, int64_t sA, int64_t sB, int32_t *d_argmin,
-               void *d_scratch, int64_t scratch_bytes, hipStream_t stream) {
+               void *d_scratch, int64_t scratch_bytes, hipStream_t stream, const Knobs &knobs) {
     if (nA == 0 || nB == 0) return WDX_SUCCESS;
     if (L <= 0) {
         set_error("DTW series length must be positive");
@@ -452,7 +452,7 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
         return WDX_ERR_INVALID;
     }
     dim3 grid((unsigned)gx, (unsigned)((nB + rpb - 1) / rpb));
-    if (L == 25 && w == 15 && !getenv("WDX_DTW_NO_SHORT")) {
+    if (L == 25 && w == 15 && !knobs.no_short_dtw) {
         hipLaunchKernelGGL((dtw_short_kernel<25, 15>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad, Lpad,
                            halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
         WDX_HIP_TRY(hipGetLastError());

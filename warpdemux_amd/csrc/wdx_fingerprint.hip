@@ -67,6 +67,20 @@ struct alignas(8) FpShared {
     double stat[6];
 };
 
+// med -/+ thresh*mad of the outlier clip (sig_proc.py:426-431): in float32 (NumPy >= 2 with a Python-float
+// threshold) or in float64 from the double threshold, rounded to float32 once (NumPy 1.x, np.float64 threshold)
+__device__ __forceinline__ void clip_bounds(const wdx_seg_params &P, float med, float mad, float &lo, float &hi) {
+    if (P.clip_bounds_f64) {
+        const double tm = P.outlier_thresh_f64 * (double)mad;
+        lo = (float)((double)med - tm);
+        hi = (float)((double)med + tm);
+    } else {
+        const float tm = P.outlier_thresh * mad;
+        lo = med - tm;
+        hi = med + tm;
+    }
+}
+
 // ---- block primitives ----------------------------------------------------------------------------
 
 __device__ __forceinline__ unsigned f32_key(float x) {
@@ -290,6 +304,119 @@ __device__ double np_pairwise_sum_dev(const double *a, int n) {
     return np_pairwise_leaf(a, n2) + np_pairwise_leaf(a + n2, n - n2);
 }
 
+// np.add.reduce over the float32 values val(0..n): NumPy's exact association -- the ufunc hands the inner loop at
+// most 8192 elements (np.getbufsize()) at a time, each chunk is summed by the pairwise routine (leaves of <= 128
+// elements with 8 accumulators, halves split at multiples of 8), chunk sums accumulate left to right.  The leaves
+// are independent: thread 0 lists them, one thread sums each, thread 0 folds them back up the same tree.
+// lstart: >= 258 unsigned, lsum: >= 257 floats, stk: >= 48 ints (all LDS).  Result to every thread.
+template <int BLOCK, class ValFn>
+__device__ float block_np_add_reduce_f32(ValFn val, int n, unsigned *lstart, float *lsum, int *stk, FpShared &sh) {
+    constexpr int kBuf = 8192;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nl = 0;
+        for (int c = 0; c < n || c == 0; c += kBuf) {
+            const int m = min(kBuf, n - c);
+            // depth-first, left before right: leaves come out in increasing start order
+            int sp = 0;
+            stk[0] = c;
+            stk[1] = m;
+            sp = 1;
+            while (sp > 0) {
+                --sp;
+                const int lo = stk[2 * sp], len = stk[2 * sp + 1];
+                if (len <= 128) {
+                    lstart[nl++] = (unsigned)lo;
+                } else {
+                    int n2 = len / 2;
+                    n2 -= n2 % 8;
+                    stk[2 * sp] = lo + n2;       // right half: popped second
+                    stk[2 * sp + 1] = len - n2;
+                    ++sp;
+                    stk[2 * sp] = lo;            // left half: popped first
+                    stk[2 * sp + 1] = n2;
+                    ++sp;
+                }
+            }
+            if (n == 0) break;
+        }
+        lstart[nl] = (unsigned)n;
+        sh.count = nl;
+    }
+    __syncthreads();
+    const int nl = sh.count;
+    for (int l = threadIdx.x; l < nl; l += BLOCK) {
+        const int lo = (int)lstart[l];
+        // a leaf ends at the next leaf's start, and never crosses an 8192-element chunk
+        const int hi = min((int)lstart[l + 1], (lo / kBuf + 1) * kBuf);
+        const int len = hi - lo;
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; ++i) res += val(lo + i);
+        } else {
+            float r0 = val(lo), r1 = val(lo + 1), r2 = val(lo + 2), r3 = val(lo + 3), r4 = val(lo + 4),
+                  r5 = val(lo + 5), r6 = val(lo + 6), r7 = val(lo + 7);
+            int i;
+            for (i = 8; i < len - (len % 8); i += 8) {
+                r0 += val(lo + i); r1 += val(lo + i + 1); r2 += val(lo + i + 2); r3 += val(lo + i + 3);
+                r4 += val(lo + i + 4); r5 += val(lo + i + 5); r6 += val(lo + i + 6); r7 += val(lo + i + 7);
+            }
+            res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+            for (; i < len; ++i) res += val(lo + i);
+        }
+        lsum[l] = res;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.0f;
+        int li = 0;
+        for (int c = 0; c < n || c == 0; c += kBuf) {
+            const int m = min(kBuf, n - c);
+            // post-order fold: frame = (len, phase), value stack alongside (float bits in the int array)
+            float ret = 0.0f;
+            int sp = 0;
+            stk[0] = m;
+            stk[1] = 0;
+            sp = 1;
+            while (sp > 0) {
+                int &len = stk[3 * (sp - 1)], &phase = stk[3 * (sp - 1) + 1], &left = stk[3 * (sp - 1) + 2];
+                if (phase == 0) {
+                    if (len <= 128) {
+                        ret = lsum[li++];
+                        --sp;
+                    } else {
+                        int n2 = len / 2;
+                        n2 -= n2 % 8;
+                        phase = 1;
+                        stk[3 * sp] = n2;
+                        stk[3 * sp + 1] = 0;
+                        ++sp;
+                    }
+                } else if (phase == 1) {
+                    left = __float_as_int(ret);
+                    phase = 2;
+                    int n2 = len / 2;
+                    n2 -= n2 % 8;
+                    stk[3 * sp] = len - n2;
+                    stk[3 * sp + 1] = 0;
+                    ++sp;
+                } else {
+                    ret = __int_as_float(left) + ret;
+                    --sp;
+                }
+            }
+            total = (c == 0) ? ret : total + ret;
+            if (n == 0) break;
+        }
+        sh.med = total;
+    }
+    __syncthreads();
+    const float out = sh.med;
+    __syncthreads();
+    return out;
+}
+
 // np.median of n <= kSegCap float64 values in LDS (no NaN) by rank counting; result via sh.stat[slot]
 template <int BLOCK>
 __device__ void block_small_median(const double *a, int n, FpShared &sh, int slot) {
@@ -400,8 +527,8 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
         const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
         const float mad =
             block_nanmedian_f32<BLOCK>([&](int i) { return fabsf(sig[i] - med); }, n, hist, sh);
-        const float tm = P.outlier_thresh * mad;
-        const float lo = med - tm, hi = med + tm;
+        float lo, hi;
+        clip_bounds(P, med, mad, lo, hi);
         const bool bad = (lo != lo) || (hi != hi);
         __syncthreads();
         for (int i = tid; i < n; i += BLOCK) {
@@ -427,8 +554,45 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
         __syncthreads();
         for (int i = tid; i < n; i += BLOCK) sig[i] = (sig[i] - shift) / scale;
         __syncthreads();
+    } else if (n > 0 && P.sig_norm == WDX_NORM_MEAN) {
+        // mean_normalize on the float32 signal (sig_proc.py:99-111, accept_nan=True): np.mean / np.std, or
+        // np.nanmean / np.nanstd when the window holds a NaN -- float32 sums in NumPy's association
+        // (oracle: mean_normalize_f32).  LDS scratch: the score curve and the event arrays are still unused.
+        float *sq = reinterpret_cast<float *>(scores);   // n floats
+        float *lsum = reinterpret_cast<float *>(ev);       // leaf sums
+        int *stk = reinterpret_cast<int *>(zz);            // traversal stack
+        unsigned vcnt = 0;
+        for (int i = tid; i < n; i += BLOCK) vcnt += (sig[i] == sig[i]);
+        unsigned gmin_, gmax_, cnt;
+        block_minmax_count<BLOCK>(0u, 0u, vcnt, sh, gmin_, gmax_, cnt);
+        const bool has_nan = cnt != (unsigned)n;
+        float shift, scale;
+        if (!has_nan) {
+            shift = block_np_add_reduce_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, lsum, stk, sh) / (float)n;
+            for (int i = tid; i < n; i += BLOCK) {
+                const float d = sig[i] - shift;
+                sq[i] = d * d;
+            }
+            scale = sqrtf(block_np_add_reduce_f32<BLOCK>([&](int i) { return sq[i]; }, n, hist, lsum, stk, sh) / (float)n);
+        } else {
+            // _replace_nan(a, 0); sums in float32; _divide_by_count forms the quotient in float64 (float32 / intp)
+            const float tot = block_np_add_reduce_f32<BLOCK>(
+                [&](int i) { const float v = sig[i]; return v == v ? v : 0.0f; }, n, hist, lsum, stk, sh);
+            shift = (float)((double)tot / (double)cnt);
+            for (int i = tid; i < n; i += BLOCK) {
+                const float v = sig[i];
+                const float d = (v == v) ? v - shift : 0.0f;
+                sq[i] = d * d;
+            }
+            const float var = (float)((double)block_np_add_reduce_f32<BLOCK>([&](int i) { return sq[i]; }, n, hist,
+                                                                             lsum, stk, sh) / (double)cnt);
+            scale = sqrtf(var);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += BLOCK) sig[i] = (sig[i] - shift) / scale;
+        __syncthreads();
     } else if (n > 0 && P.sig_norm != WDX_NORM_NONE) {
-        finish(WDX_READ_FAIL_SIGNORM);  // host rejects WDX_NORM_MEAN up front; unknown codes fail here
+        finish(WDX_READ_FAIL_SIGNORM);  // unknown codes fail here
         return;
     }
 
@@ -748,8 +912,8 @@ static size_t fp_lds_bytes(int cap) {
 
 template <int BLOCK, bool PROF>
 static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream, int64_t *n_launches) {
-    WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_kernel<BLOCK, PROF>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static LdsAttr attr;
+    if (int rc = attr.ensure(fingerprint_kernel<BLOCK, PROF>, lds)) return rc;
     // HIP drops work when grid.x * block.x reaches 2^32: launch in slices of 2^21 reads
     const int64_t slice = 1 << 21;
     for (int64_t base = 0; base < A.n_reads; base += slice) {
@@ -766,8 +930,8 @@ static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream, int64_t *n
 template <int BLOCK>
 static int launch_fp_list(const FpArgs &A, size_t lds, const unsigned *count, const int32_t *list,
                           hipStream_t stream) {
-    WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_list_kernel<BLOCK>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static LdsAttr attr;
+    if (int rc = attr.ensure(fingerprint_list_kernel<BLOCK>, lds)) return rc;
     const int64_t grid = A.n_reads < 2048 ? A.n_reads : 2048;
     hipLaunchKernelGGL((fingerprint_list_kernel<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), lds, stream,
                        A, count, list);
@@ -781,8 +945,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
-                       hipStream_t stream, void *d_ws, int64_t *n_launches, long long *d_prof,
-                       int64_t prof_reads, int stop_phase) {
+                       hipStream_t stream, void *d_ws, const Knobs &knobs, int64_t *n_launches,
+                       long long *d_prof, int64_t prof_reads, int stop_phase) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (n_reads > 0x7fffffffLL) {
         set_error("at most 2^31-1 reads per call");
@@ -798,10 +962,6 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     }
     if (p.running_stat_width < 0 || p.running_stat_width > kMaxW) {
         set_error("running_stat_width must be in [0, %d]", kMaxW);
-        return WDX_ERR_UNSUPPORTED;
-    }
-    if (p.sig_norm == WDX_NORM_MEAN) {
-        set_error("sig_extract.normalization=\"mean\" is not implemented by the HIP engine");
         return WDX_ERR_UNSUPPORTED;
     }
     if (p.padding < 0) {
@@ -828,7 +988,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
                          p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
-                         !getenv("WDX_FORCE_SLOW");
+                         !knobs.exact_path;
     if (fast_ok) {
         // samples per thread: the smaller instantiation when the longest adapter window allows it;
         // windows beyond 6144 samples take the slow path
@@ -840,7 +1000,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // per CU for the 89 % of reads that fit it was measured: no gain, the kernel is issue-bound
         // from four workgroups on.)
         int capP = small_fast ? 1152 : 1376;
-        if (const char *e = getenv("WDX_FAST_CAPP")) capP = atoi(e);  // experiment knob
+        if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow list, [1] big list
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
@@ -854,9 +1014,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         void (*kern)(FastArgs) = nullptr;
         if (d_prof) kern = small_fast ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptLarge, true>;
         else kern = small_fast ? fingerprint_fast_kernel<kNptSmall, false> : fingerprint_fast_kernel<kNptLarge, false>;
-        WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)flds));
-        if (getenv("WDX_DEBUG_OCC")) {
+        static LdsAttr attr_fast[4];
+        if (int rc = attr_fast[(d_prof ? 2 : 0) + (small_fast ? 1 : 0)].ensure(kern, flds)) return rc;
+        if (knobs.debug_occ) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
             fprintf(stderr, "[wdx] fast kernel capF=%d capP=%d lds=%zu B -> %d workgroups/CU\n", capF, capP, flds, nb);
@@ -872,8 +1032,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int capF2 = 8192, capP2 = 1856;
             const size_t flds2 = fast_lds_bytes(capF2, capP2);
             FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big};
-            WDX_HIP_TRY(hipFuncSetAttribute((const void *)fingerprint_fast_list_kernel<kNptHuge>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
+            static LdsAttr attr_huge;
+            if (int rc = attr_huge.ensure(fingerprint_fast_list_kernel<kNptHuge>, flds2)) return rc;
             const int64_t grid = n_reads < 1024 ? n_reads : 1024;
             hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2, stream,
                                F2);

@@ -345,14 +345,15 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
 }
 
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
-                       double *d_conf, hipStream_t stream) {
+                       double *d_conf, hipStream_t stream, const Knobs &knobs) {
     if (n == 0) return WDX_SUCCESS;
     const int k = M.k;
-    if (k >= 2 && k <= 16 && !getenv("WDX_SVM_NO_MFMA")) {
+    if (k >= 2 && k <= 16 && !knobs.svm_scalar) {
         const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (size_t)k * k);
         void (*kern)(SvmDev, const float *, int64_t, double *, int32_t *, double *) =
             M.pwr == 1 ? svm_predict_mfma_kernel<true> : svm_predict_mfma_kernel<false>;
-        WDX_HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        static LdsAttr attr[2];
+        if (int rc = attr[M.pwr == 1].ensure(kern, lds2)) return rc;
         const int64_t tiles = (n + 15) / 16;
         const int64_t slice = (1ll << 31) / 64;
         for (int64_t base = 0; base < tiles; base += slice) {
@@ -370,8 +371,8 @@ int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *
         set_error("SVM model too large for the LDS carve-up (%zu B)", lds);
         return WDX_ERR_UNSUPPORTED;
     }
-    WDX_HIP_TRY(hipFuncSetAttribute((const void *)svm_predict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+    static LdsAttr attr_scalar;
+    if (int rc = attr_scalar.ensure(svm_predict_kernel, lds)) return rc;
     const int64_t slice = (1ll << 31) / 256;
     for (int64_t base = 0; base < n; base += slice) {
         const int64_t m = n - base < slice ? n - base : slice;

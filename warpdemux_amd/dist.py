@@ -57,11 +57,89 @@ def reduce_counts(counts):
     return counts
 
 
+class CountReducer:
+    """The path's one exchange: in-place SUM of the int64 call histogram over all ranks.
+
+    ``mode == "rccl"``: the C ABI's own communicator (``wdx_comm_init`` / ``wdx_reduce_counts``,
+    include/wdx.h) -- rank 0 draws the id with ``wdx_comm_unique_id`` and the 128 bytes travel over the
+    already initialised torch.distributed group (any side channel would do).  ``mode == "torch"``:
+    ``torch.distributed.all_reduce`` on the process group (gloo in the CPU tests; nccl = RCCL too).
+    ``mode == "single"``: one process, nothing to do.  ``prefer`` = "rccl" | "torch" | None (rccl when
+    the group's backend is nccl and the engine is on a GPU)."""
+
+    def __init__(self, ctx=None, prefer: str | None = None):
+        import torch.distributed as dist
+
+        self.ctx = ctx
+        self.mode = "single"
+        self.note = ""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        self.mode = "torch"
+        want_rccl = prefer == "rccl" or (prefer is None and dist.get_backend() == "nccl")
+        if want_rccl and ctx is not None:
+            try:
+                self._init_rccl(dist)
+                self.mode = "rccl"
+            except Exception as e:  # noqa: BLE001 -- fall back to the process group, and say so
+                self.note = f"wdx_comm_init unavailable ({type(e).__name__}: {e}); torch.distributed used"
+        # every rank must take the same road
+        import torch
+
+        flag = torch.tensor([1 if self.mode == "rccl" else 0], dtype=torch.int32,
+                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if self.mode == "rccl" and int(flag.item()) == 0:
+            self._L.wdx_comm_destroy(self.ctx.handle)
+            self.mode = "torch"
+
+    def _init_rccl(self, dist):
+        import ctypes as C
+
+        from . import _lib
+
+        self._L = L = _lib.load()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(L.wdx_comm_unique_id(buf))
+            ident[0] = bytes(buf.raw)
+        dist.broadcast_object_list(ident, src=0)
+        _lib.check(L.wdx_comm_init(self.ctx.handle, ident[0], rank, world))
+
+    def __call__(self, counts, stream=None):
+        """counts: int64 torch tensor (device tensor for "rccl"); reduced in place."""
+        if self.mode == "rccl":
+            import ctypes as C
+
+            from . import _lib
+
+            if counts.device.type != "cuda":
+                raise ValueError("wdx_reduce_counts needs the device histogram")
+            _lib.check(self._L.wdx_reduce_counts(self.ctx.handle, C.c_void_p(counts.data_ptr()),
+                                                 int(counts.numel()), stream))
+            return counts
+        if self.mode == "torch":
+            return reduce_counts(counts)
+        return counts
+
+    def close(self):
+        if self.mode == "rccl":
+            self._L.wdx_comm_destroy(self.ctx.handle)
+            self.mode = "torch"
+
+
 def barrier():
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def min_over_ranks(value: float, device=None) -> float:
+    """MIN all-reduce of a host scalar (agreement between ranks)."""
+    return -max_over_ranks(-value, device)
 
 
 def max_over_ranks(value: float, device=None) -> float:

@@ -45,6 +45,11 @@ class SegParams:
     accept_less_cpts: bool = False
     seg_norm: str = "mean"
     barcode_num_events: int = 25
+    # evaluation of the clip bounds `med -/+ thresh*mad` (sig_proc.py:426-431), the one NumPy-version-dependent
+    # step of the path: "float32" (NumPy >= 2 with a Python-float threshold), "float64" (NumPy 1.x -- the
+    # reference pins 1.26.4 -- or an np.float64 threshold), "auto" = the rule of the NumPy this process runs,
+    # i.e. what the reference would compute here
+    clip_bounds: str = "auto"
 
     @classmethod
     def from_spc(cls, spc) -> "SegParams":
@@ -58,7 +63,8 @@ class SegParams:
         return cls(
             padding=int(spc.sig_extract.padding),
             sig_norm=str(spc.sig_extract.normalization),
-            outlier_thresh=float(spc.core.sig_norm_outlier_thresh),
+            outlier_thresh=(spc.core.sig_norm_outlier_thresh if isinstance(spc.core.sig_norm_outlier_thresh, np.float64)
+                            else float(spc.core.sig_norm_outlier_thresh)),
             min_obs_per_base=int(seg.min_obs_per_base),
             running_stat_width=int(seg.running_stat_width),
             num_events=int(seg.num_events),
@@ -72,10 +78,15 @@ class SegParams:
             if name not in _lib.NORM_CODES:
                 msg = f"Normalization method {name} not recognized."
                 raise ValueError(msg)
+        if self.clip_bounds not in ("auto", "float32", "float64"):
+            raise ValueError("clip_bounds must be 'auto', 'float32' or 'float64'")
+        f64 = (self.clip_bounds == "float64" or
+               (self.clip_bounds == "auto" and (isinstance(self.outlier_thresh, np.float64)
+                                                or int(np.__version__.split(".")[0]) < 2)))
         return _lib.SegParamsC(
-            self.padding, _lib.NORM_CODES[self.sig_norm], self.outlier_thresh, self.min_obs_per_base,
+            self.padding, _lib.NORM_CODES[self.sig_norm], float(self.outlier_thresh), self.min_obs_per_base,
             self.running_stat_width, self.num_events, int(self.accept_less_cpts),
-            _lib.NORM_CODES[self.seg_norm], self.barcode_num_events,
+            _lib.NORM_CODES[self.seg_norm], self.barcode_num_events, int(f64), float(self.outlier_thresh),
         )
 
 
@@ -234,17 +245,23 @@ def demux_batch(signals, adapter_start, adapter_end, params: SegParams, success=
     ok = None if success is None else np.ascontiguousarray(success, dtype=np.uint8)
     pc = params.to_c()
     K = params.barcode_num_events
-    if want_dist and n_refs is None:
-        raise ValueError("n_refs (number of resident references) is needed to size the distance matrix")
-    dist = np.empty((n, n_refs), dtype=np.float32) if want_dist else None
+    ctx = _lib.default_context(device)
+    held = getattr(ctx, "_demux_refs", None)
+    if held is None:
+        raise _lib.WdxError("demux_batch: no reference set -- call set_references() first")
+    # the distance matrix is sized from the set this context holds, never from the caller (the C ABI checks
+    # it against the resident set once more)
+    n_held = int(held[0].shape[0])
+    if n_refs is not None and int(n_refs) != n_held:
+        raise ValueError(f"n_refs={n_refs} but set_references() installed {n_held} references")
+    dist = np.empty((n, n_held), dtype=np.float32) if want_dist else None
     fpt = np.empty((n, K), dtype=np.float64) if want_fpt else None
     call = np.empty(n, dtype=np.int32)
     status = np.empty(n, dtype=np.int32)
-    ctx = _lib.default_context(device)
     _ensure_references(ctx)
     _lib.check(_lib.load().wdx_demux_batch(
         ctx.handle, _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e), _lib.ptr(ok), C.byref(pc),
-        _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call), _lib.ptr(status)))
+        n_held, _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call), _lib.ptr(status)))
     return DemuxBatch(status, call, dist, fpt)
 
 
