@@ -83,6 +83,30 @@ def spawn_ranks(args) -> int:
 # ----------------------------------------------------------------------------------------------------
 # CPU baseline = the oracle (a port of the reference's CPU path) on the host cores, and the parity gate
 # ----------------------------------------------------------------------------------------------------
+def effective_cores() -> int:
+    """CPUs this process may actually use: the affinity mask and the cgroup CPU quota both bound os.cpu_count()
+    (the GPU boxes show 256 logical CPUs behind a 16-CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _oracle_minibatch(job):
     """One <=1000-read minibatch driven like file_proc.py:418-450: per-read fingerprints, then one
     distance_matrix_to(n_jobs=1) call and the nearest-reference call.  Runs in a worker THREAD (ctypes
@@ -111,7 +135,7 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
     import torch
     from concurrent.futures import ThreadPoolExecutor
 
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     chunk = 32768
     mb = 1000 if cores * 1000 <= chunk else max(64, chunk // cores)
     t_cpu = 0.0
@@ -169,6 +193,7 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
         "value": n_done / t_cpu if t_cpu > 0 else None,
         "unit": "reads/s",
         "cores": cores,
+        "logical_cpus": os.cpu_count(),
         "kind": "port",
         "sample": ("first %d reads of the same workload; oracle/wdx_oracle.c (C restatement of sig_proc.py:394-605 + "
                    "dtaidistance's banded DTW) driven as %d-read minibatches like file_proc.py:418-450, one worker thread "
@@ -231,7 +256,7 @@ def _oracle_dtw_threads(X, Y, budget_s=3.0, rows_per_job=32):
 
     from oracle import wdx_oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     outs, done, t0 = [], 0, time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         while done < X.shape[0] and (done == 0 or time.perf_counter() - t0 < budget_s):
