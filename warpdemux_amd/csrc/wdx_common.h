@@ -62,14 +62,16 @@ struct DtwRefs {  // resident reference set, both layouts (see DESIGN.md "DTW da
     uint64_t content_hash = 0;
 };
 
-// lanes run over the columns of AT (L, ldA) [nA series]; the uniform operand is Bpad (nB rows).
+// lanes run over the columns of AT (L, ldA) [nA series] -- or, with a_rowmajor, over the rows of an (nA, L)
+// row-major array (ldA ignored; a_nan may be null: the kernel flags NaN series itself); the uniform operand is
+// Bpad (nB rows).
 // out[a*sA + b*sB] = (float)dtw(a, b).  d_argmin (nullable) is only legal when the lanes are the
 // reads (sA == nB, sB == 1): int32[nA].
 int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan /*nullable*/,
                const double *Bpad, int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan,
                int64_t L, int window, double penalty, float *out, int64_t sA, int64_t sB,
                int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream,
-               const Knobs &knobs);
+               const Knobs &knobs, bool a_rowmajor = false);
 int64_t dtw_scratch_bytes(int64_t L, int window);
 // anti-diagonal wavefront kernel for small problems (latency path)
 bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window, const Knobs &knobs);

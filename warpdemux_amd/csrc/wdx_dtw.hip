@@ -109,7 +109,24 @@ struct ArgminAcc {
     }
 };
 
-template <int W, bool EXACT_W>
+// true when the float64 row holds a NaN: lane-private sweep of a row-major series (16-byte loads)
+__device__ __forceinline__ bool row_has_nan(const double *__restrict__ row, int L) {
+    bool f = false;
+    int i = 0;
+    for (; i + 2 <= L; i += 2) {
+        const double a = row[i], b = row[i + 1];
+        f |= (a != a) | (b != b);
+    }
+    if (i < L) f |= row[i] != row[i];
+    return f;
+}
+
+// ROWMAJOR: the a-series arrive as they are produced -- (nA, L) row-major, a lane reads its OWN row (ldA is
+// ignored).  Loads of one lane are contiguous, so the body rows are fetched eight at a time with 16-byte
+// loads (one 64-byte sector per lane and chunk instead of one per row) one chunk ahead of the recurrence,
+// and the NaN flag of the series is computed here when the caller has none: no transposed copy of the
+// fingerprints, no separate flag kernel.
+template <int W, bool EXACT_W, bool ROWMAJOR>
 __global__ __launch_bounds__(64) void dtw_band_kernel(
     const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
     const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
@@ -121,8 +138,9 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
     const int64_t al = active ? a : nA - 1;
     const int b0 = blockIdx.y * refs_per_block;
     const int b1 = min(nB, b0 + refs_per_block);
-    const bool anan = a_nan ? (a_nan[al] != 0) : false;
-    const double *__restrict__ xp = AT + al;
+    if (ROWMAJOR) ldA = 1;
+    const double *__restrict__ xp = ROWMAJOR ? AT + al * (int64_t)L : AT + al;
+    const bool anan = a_nan ? (a_nan[al] != 0) : (ROWMAJOR ? row_has_nan(xp, L) : false);
     ArgminAcc acc;
 
     for (int b = b0; b < b1; ++b) {
@@ -137,8 +155,34 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
             // head and tail rows from templates (no masks, no cells outside the matrix); loads of x are
             // independent of the recurrence and get hoisted by the compiler
             dtw_head_rows<W>(r, xp, ldA, y, p2, std::make_integer_sequence<int, W - 1>{});
-            xn = xp[(int64_t)(W - 1) * ldA];
-            for (i = W - 1; i < L - W + 1; ++i) {
+            i = W - 1;
+            if (ROWMAJOR) {
+                constexpr int CH = 8;
+                const int body_end = L - W + 1;
+                if (i + CH <= body_end) {
+                    double xc[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) xc[k] = xp[i + k];
+                    for (; i + CH <= body_end; i += CH) {
+                        double xq[CH];
+                        const bool more = i + 2 * CH <= body_end;  // wave-uniform
+                        if (more) {
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) xq[k] = xp[i + CH + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) dtw_row<W, false>(r, xc[k], y + i + k, p2, 0, 0, 0);
+                        if (more) {
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) xc[k] = xq[k];
+                        }
+                    }
+                }
+                if (i < body_end) xn = xp[i];
+            } else {
+                xn = xp[(int64_t)(W - 1) * ldA];
+            }
+            for (; i < L - W + 1; ++i) {
                 const double x = xn;
                 xn = xp[(int64_t)(i + 1) * ldA];  // i + 1 <= L - W + 1 < L
                 dtw_row<W, false>(r, x, y + i, p2, 0, 0, 0);
@@ -212,7 +256,7 @@ __device__ __forceinline__ void dtw_short_rows(double (&D)[L], const double (&x)
     (dtw_short_row<L, W, Is>(D, x[Is], y, p2), ...);
 }
 
-template <int L, int W>
+template <int L, int W, bool ROWMAJOR>
 __global__ __launch_bounds__(64) void dtw_short_kernel(
     const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
     const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
@@ -223,10 +267,14 @@ __global__ __launch_bounds__(64) void dtw_short_kernel(
     const int64_t al = active ? a : nA - 1;
     const int b0 = blockIdx.y * refs_per_block;
     const int b1 = min(nB, b0 + refs_per_block);
-    const bool anan = a_nan ? (a_nan[al] != 0) : false;
     double x[L];
+    bool anan = a_nan ? (a_nan[al] != 0) : false;
 #pragma unroll
-    for (int i = 0; i < L; ++i) x[i] = AT[(int64_t)i * ldA + al];
+    for (int i = 0; i < L; ++i) x[i] = ROWMAJOR ? AT[al * (int64_t)L + i] : AT[(int64_t)i * ldA + al];
+    if (ROWMAJOR && !a_nan) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) anan |= x[i] != x[i];
+    }
     ArgminAcc acc;
     for (int b = b0; b < b1; ++b) {
         const double *__restrict__ y = Bpad + (int64_t)b * Lpad + halo;
@@ -402,7 +450,8 @@ bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window, const
 int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, const double *Bpad,
                int64_t Lpad, int halo, int64_t nB, const uint8_t *b_nan, int64_t L, int window,
                double penalty, float *out, int64_t sA, int64_t sB, int32_t *d_argmin,
-               void *d_scratch, int64_t scratch_bytes, hipStream_t stream, const Knobs &knobs) {
+               void *d_scratch, int64_t scratch_bytes, hipStream_t stream, const Knobs &knobs,
+               bool a_rowmajor) {
     if (nA == 0 || nB == 0) return WDX_SUCCESS;
     if (L <= 0) {
         set_error("DTW series length must be positive");
@@ -411,6 +460,10 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
     int w = (window <= 0 || window > L) ? (int)L : window;  // |i-j| <= w-1 is vacuous beyond L
     const double p2 = penalty * penalty;
     if (w > kMaxRegWindow) {
+        if (a_rowmajor) {
+            set_error("the scratch-row DTW path takes the read-minor layout");
+            return WDX_ERR_INVALID;
+        }
         const int64_t nT = 65536;
         if (scratch_bytes < dtw_scratch_bytes(L, w) || !d_scratch) {
             set_error("DTW scratch too small for window %d", w);
@@ -453,15 +506,27 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
     }
     dim3 grid((unsigned)gx, (unsigned)((nB + rpb - 1) / rpb));
     if (L == 25 && w == 15 && !knobs.no_short_dtw) {
-        hipLaunchKernelGGL((dtw_short_kernel<25, 15>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad, Lpad,
-                           halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
+        if (a_rowmajor)
+            hipLaunchKernelGGL((dtw_short_kernel<25, 15, true>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad,
+                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
+        else
+            hipLaunchKernelGGL((dtw_short_kernel<25, 15, false>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad,
+                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
         WDX_HIP_TRY(hipGetLastError());
         if (d_argmin && !fused_argmin) return launch_argmin(out, nA, nB, d_argmin, stream);
         return WDX_SUCCESS;
     }
-#define WDX_LAUNCH_BAND(WW, EX)                                                                   \
-    hipLaunchKernelGGL((dtw_band_kernel<WW, EX>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, \
-                       Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB, fused_argmin, rpb)
+#define WDX_LAUNCH_BAND(WW, EX)                                                                          \
+    do {                                                                                                 \
+        if (a_rowmajor)                                                                                  \
+            hipLaunchKernelGGL((dtw_band_kernel<WW, EX, true>), grid, dim3(64), 0, stream, AT, ldA, nA,  \
+                               a_nan, Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB,      \
+                               fused_argmin, rpb);                                                       \
+        else                                                                                             \
+            hipLaunchKernelGGL((dtw_band_kernel<WW, EX, false>), grid, dim3(64), 0, stream, AT, ldA, nA, \
+                               a_nan, Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB,      \
+                               fused_argmin, rpb);                                                       \
+    } while (0)
     if (w == 15) {
         WDX_LAUNCH_BAND(15, true);
     } else if (w <= 8) {
