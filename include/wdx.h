@@ -54,6 +54,7 @@ extern "C" {
 #define WDX_READ_FAIL_SEGMENT 3 /* "event segmentation failed"    sig_proc.py:537-544           */
 #define WDX_READ_FAIL_SEGNORM 4 /* "segment normalization failed" sig_proc.py:546-560           */
 #define WDX_READ_FAIL_UNKNOWN 5 /* exception -> "unknown"         file_proc.py:209-224          */
+#define WDX_READ_FAIL_CONSENSUS 6 /* "consensus query outlier"    sig_proc.py:497-512 (refinement) */
 
 /* normalisation selectors (sig_proc.py:114-136) */
 #define WDX_NORM_NONE 0
@@ -162,6 +163,32 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                         int64_t *d_dwell, double *d_stats, int32_t *d_status, void *stream);
 
 #define WDX_MAX_ADAPTER_SAMPLES 11200
+
+/* ---- N3: consensus-guided barcode refinement (tRNA models) -- detect_results_to_fpt with
+ *      segmentation.consensus_refinement = True (sig_proc.py:257-378, 452-521): segment the adapter, find the
+ *      constant adapter part by subsequence DTW of a consensus signal against the normalised event means
+ *      (dtaidistance warping_paths_fast + SubsequenceAlignment.best_match in the reference), re-segment the score
+ *      curve behind it into barcode events, normalise them with the ADAPTER's mean/std (normalize_wrt). */
+typedef struct wdx_refine_params {
+    const double *query;          /* consensus signal (warpdemux/_consensus.py ALL[consensus_model]); HOST pointer   */
+    int32_t n_query;              /* 1..96                                                                         */
+    int32_t subseq_norm;          /* segmentation.consensus_subseq_match_normalization (WDX_NORM_*)                 */
+    double penalty;               /* segmentation.consensus_subseq_match_penalty (un-squared)                      */
+    int32_t psi[4];               /* segmentation.consensus_subseq_match_psi: relaxation at the begin / end of the
+                                     query and the begin / end of the series (the two end values do not enter the
+                                     matching function the reference reads)                                        */
+    int32_t ub_start, lb_end, ub_end; /* consensus_subseq_match_ub_start / lb_end / ub_end (outlier filter)         */
+    int32_t barcode_segm_events;  /* barcode_num_events[0]: events detected in the barcode tail                     */
+    int32_t barcode_keep_events;  /* barcode_num_events[1]: events kept = K of fpt / dwell                          */
+} wdx_refine_params;
+/* As wdx_fingerprint_batch; K = rp->barcode_keep_events (p->barcode_num_events is ignored); stats are the ADAPTER's;
+ * refine_idx (n_reads, 3) int32 = {seg_cons_query_start, seg_cons_query_end, sig_barcode_start} (-1 when the read
+ * failed earlier).  Status WDX_READ_FAIL_CONSENSUS still reports stats and refine_idx, like the reference's
+ * ReadResult.  Limits: num_events <= 127, refinement_optimal_cpts (ruptures KernelCPD) -> not offered. */
+int wdx_fingerprint_refine_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                                 const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                                 const wdx_seg_params *p, const wdx_refine_params *rp, double *fpt, int64_t *dwell,
+                                 double *stats, int32_t *refine_idx, int32_t *status);
 
 /* ---- fused path: raw adapter rows -> fingerprint -> DTW to the resident refs -> call ------ */
 

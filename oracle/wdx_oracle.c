@@ -687,6 +687,243 @@ int wdx_oracle_normalize_wrt(const double *to_norm, int64_t m, const double *ref
     return r_;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* N3: consensus-guided barcode refinement (sig_proc.py:257-378, 452-521) -- tRNA models        */
+/* ------------------------------------------------------------------------------------------ */
+/* PARITY of the subsequence match: UNPINNED.  `_get_subseq_match` (sig_proc.py:287-306) calls
+ * dtaidistance==2.3.13 (absent, see header): dtw.warping_paths_fast(query, series, penalty, psi,
+ * compact=False, psi_neg=False), SubsequenceAlignment._compute_matching() and .best_match().segment.
+ * Restated from the library's published algorithm:
+ *   wps[0][0..psi_2b] = 0, wps[0..psi_1b][0] = 0, everything else +inf; window = max(l1, l2) (none);
+ *   wps[i+1][j+1] = (q[i] - s[j])^2 + min(wps[i][j], wps[i][j+1] + penalty^2, wps[i+1][j] + penalty^2);
+ *   paths = sqrt(wps) elementwise;
+ *   matching[j] = paths[l1][j+1] / l1;  best = argmin(matching) (first minimum) = segment end;
+ *   segment start = column of the first cell of dtw.best_path(paths, col=best+1): from (l1, best+1) step
+ *   to argmin(paths[i-1][j-1], paths[i-1][j], paths[i][j-1]) (first minimum: diagonal, up, left) while
+ *   i > 0 and j > 0; the last cell visited with i >= 1 and j >= 1 is the path's first element.
+ * Everything around it (re-segmentation of the score tail, normalize_wrt, the outlier filter, the stats)
+ * is the reference's own code and is pinned by fixture g8 (tests/golden/make_golden_refine.py). */
+typedef struct {
+    const double *query;   /* consensus signal (warpdemux/_consensus.py), n_query points            */
+    int32_t n_query;
+    int32_t subseq_norm;   /* consensus_subseq_match_normalization: 0 none, 1 mean, 2 median         */
+    double penalty;        /* consensus_subseq_match_penalty (un-squared)                           */
+    int32_t psi[4];        /* consensus_subseq_match_psi: begin/end of the query, begin/end of the series */
+    int32_t ub_start, lb_end, ub_end; /* consensus_subseq_match_ub_start / lb_end / ub_end          */
+    int32_t barcode_segm_events;      /* barcode_num_events[0]: events detected in the barcode tail  */
+    int32_t barcode_keep_events;      /* barcode_num_events[1]: events kept (K of the outputs)       */
+} wdx_refine_params;
+
+#define WDX_FAIL_CONSENSUS 6 /* "consensus query outlier", sig_proc.py:492-512 */
+
+/* -> 0, or -1 when the library would misbehave (empty inputs). start/end as SAMatch.segment. */
+int wdx_oracle_subseq_match(const double *q, int64_t l1, const double *s, int64_t l2, double penalty,
+                            int64_t psi_1b, int64_t psi_2b, int64_t *start, int64_t *end) {
+    if (l1 < 1 || l2 < 1) return -1;
+    const int64_t cols = l2 + 1;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(l1 + 1) * (size_t)cols);
+    const double p2 = penalty * penalty;
+    for (int64_t i = 0; i <= l1; i++)
+        for (int64_t j = 0; j <= l2; j++) w[i * cols + j] = INFINITY;
+    for (int64_t j = 0; j <= psi_2b && j <= l2; j++) w[j] = 0.0;
+    for (int64_t i = 0; i <= psi_1b && i <= l1; i++) w[i * cols] = 0.0;
+    for (int64_t i = 0; i < l1; i++)
+        for (int64_t j = 0; j < l2; j++) {
+            double d = q[i] - s[j];
+            d = d * d;
+            double m = w[i * cols + j];
+            double t = w[i * cols + j + 1] + p2;
+            if (t < m) m = t;
+            t = w[(i + 1) * cols + j] + p2;
+            if (t < m) m = t;
+            w[(i + 1) * cols + j + 1] = d + m;
+        }
+    for (int64_t k = 0; k < (l1 + 1) * cols; k++) w[k] = sqrt(w[k]);
+    int64_t best = 0;
+    double bv = w[l1 * cols + 1] / (double)l1;
+    for (int64_t j = 1; j < l2; j++) {
+        double v = w[l1 * cols + j + 1] / (double)l1;
+        if (v < bv) { bv = v; best = j; }   /* np.argmin: first minimum; NaN cannot occur (no NaN inputs) */
+    }
+    int64_t i = l1, j = best + 1, sj = j;
+    while (i > 0 && j > 0) {
+        sj = j;
+        double a = w[(i - 1) * cols + j - 1], b = w[(i - 1) * cols + j], c = w[i * cols + j - 1];
+        int arg = 0;
+        double mv = a;
+        if (b < mv) { mv = b; arg = 1; }
+        if (c < mv) { arg = 2; }
+        if (arg == 0) { i--; j--; }
+        else if (arg == 1) i--;
+        else j--;
+    }
+    *start = sj - 1;
+    *end = best;
+    free(w);
+    return 0;
+}
+
+/* detect_results_to_fpt with segmentation.consensus_refinement = True.  Outputs: fpt[Kk], dwell[Kk],
+ * stats[6], idx[3] = {seg_cons_query_start, seg_cons_query_end, sig_barcode_start}; Kk = keep events.
+ * Status 6 ("consensus query outlier") still fills stats and idx (sig_proc.py:497-512). */
+static int fingerprint_refine_one_impl(const float *row, int64_t row_len, int32_t a_start, int32_t a_end, int ok,
+                                       const wdx_seg_params *p, const wdx_refine_params *rp, double *fpt,
+                                       int64_t *dwell, double *stats, int32_t *idx) {
+    if (!ok) return WDX_FAIL_DETECT;
+    int64_t start = (int64_t)a_start - p->padding;
+    if (start < 0) start = 0;
+    int64_t stop = (int64_t)a_end + p->padding;
+    if (stop > row_len) stop = row_len;
+    int64_t n = stop - start;
+    if (n < 0) n = 0;
+    int status = WDX_OK;
+    int64_t E = p->num_events, E2 = rp->barcode_segm_events, Kk = rp->barcode_keep_events;
+    float *sig = (float *)a_alloc(sizeof(float) * (size_t)(n + 1) * 2);
+    float *scratch = sig + n + 1;
+    double *x = (double *)a_alloc(sizeof(double) * (size_t)(n + 1) * 2);
+    double *scores = x + n + 1;
+    int64_t *cpts = (int64_t *)a_alloc(sizeof(int64_t) * (size_t)(E + E2 + 4));
+    int64_t *cpts2 = cpts + E + 2;
+    double *ev = (double *)a_alloc(sizeof(double) * (size_t)(E + E2 + 4) * 4);
+    double *tmp = ev + (E + 2), *tmp2 = tmp + (E + 2), *nrm = tmp2 + (E + 2);
+    double *ev2 = nrm + (E + 2);
+    memcpy(sig, row + start, sizeof(float) * (size_t)n);
+    /* A1 clip, A2 signal normalisation: as in the plain branch */
+    float med = nanmedian_f32(sig, n, scratch);
+    {
+        float *dev = (float *)a_alloc(sizeof(float) * (size_t)(n + 1));
+        for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - med);
+        float mad = nanmedian_f32(dev, n, scratch);
+        float lo, hi;
+        if (p->clip_bounds_f64) {
+            double tm = p->outlier_thresh_f64 * (double)mad;
+            lo = (float)((double)med - tm);
+            hi = (float)((double)med + tm);
+        } else {
+            float tm = p->outlier_thresh * mad;
+            lo = med - tm;
+            hi = med + tm;
+        }
+        for (int64_t i = 0; i < n; i++) {
+            float v = sig[i];
+            if (v != v) continue;
+            if (lo != lo || hi != hi) { sig[i] = NAN; continue; }
+            if (!(v > lo)) v = lo;
+            if (!(v < hi)) v = hi;
+            sig[i] = v;
+        }
+    }
+    if (n > 0 && p->sig_norm != 0) {
+        if (p->sig_norm == 1) mean_normalize_f32(sig, n, scratch);
+        else if (p->sig_norm == 2) {
+            float shift = nanmedian_f32(sig, n, scratch);
+            float *dev = (float *)a_alloc(sizeof(float) * (size_t)(n + 1));
+            for (int64_t i = 0; i < n; i++) dev[i] = fabsf(sig[i] - shift);
+            float scale = nanmedian_f32(dev, n, scratch);
+            for (int64_t i = 0; i < n; i++) sig[i] = (sig[i] - shift) / scale;
+        } else { status = WDX_FAIL_SIGNORM; goto done; }
+    }
+    {
+        if (E <= 0) { status = WDX_FAIL_UNKNOWN; goto done; }
+        /* sig_proc.py:311-320: int(round(...)) */
+        int64_t d = py_round((double)n / (double)E / 2.0);
+        if (p->min_obs_per_base < d) d = p->min_obs_per_base;
+        int64_t w = py_round((double)n / (double)E);
+        if (p->running_stat_width < w) w = p->running_stat_width;
+        for (int64_t i = 0; i < n; i++) x[i] = (double)sig[i];
+        int64_t ns = wdx_oracle_windowed_t_test(x, n, w, scores);
+        if (ns < 0) ns = 0;
+        int64_t nc = wdx_oracle_scores_to_cpts(scores, ns, E, d, w, p->accept_less_cpts, cpts);
+        if (nc < 0) { status = WDX_FAIL_UNKNOWN; goto done; }
+        if (nc == 0) { status = WDX_FAIL_SEGMENT; goto done; }
+        int64_t nseg = nc - 1;
+        wdx_oracle_new_means(x, cpts, nseg, ev);
+        if (nseg == 0) { status = WDX_FAIL_SEGMENT; goto done; }
+        /* _get_subseq_match: normalize(series, method) with accept_nan=False -> ValueError escapes
+         * detect_results_to_fpt -> "unknown" (file_proc.py:220-224) */
+        for (int64_t i = 0; i < nseg; i++)
+            if (ev[i] != ev[i]) { status = WDX_FAIL_UNKNOWN; goto done; }
+        if (rp->subseq_norm == 1) {
+            double mean = np_mean_f64(ev, nseg), sd = np_std_f64(ev, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) nrm[i] = (ev[i] - mean) / sd;
+        } else if (rp->subseq_norm == 2) {
+            double m = median_f64(ev, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(ev[i] - m);
+            double sc = median_f64(tmp2, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) nrm[i] = (ev[i] - m) / sc;
+        } else if (rp->subseq_norm == 0) {
+            for (int64_t i = 0; i < nseg; i++) nrm[i] = ev[i];
+        } else { status = WDX_FAIL_UNKNOWN; goto done; }
+        for (int64_t i = 0; i < nseg; i++)
+            if (nrm[i] != nrm[i]) { status = WDX_FAIL_UNKNOWN; goto done; } /* constant series: 0/0 -> the library's C code would
+                                                                               propagate NaN; treated as unknown (unpinned) */
+        int64_t qs = 0, qe = 0;
+        if (wdx_oracle_subseq_match(rp->query, rp->n_query, nrm, nseg, rp->penalty, rp->psi[0], rp->psi[2], &qs, &qe)) {
+            status = WDX_FAIL_UNKNOWN;
+            goto done;
+        }
+        int64_t sbs = cpts[qe]; /* int(np.sum(adapter_dwell_times[:seg_query_end])) */
+        /* barcode tail: discrepenacy_curve_to_cpts(adapter_scores[sbs:], E2, config d, config W, accept_less=False) */
+        int64_t ns2 = ns - sbs;
+        if (ns2 < 0) ns2 = 0;
+        int64_t nc2 = wdx_oracle_scores_to_cpts(scores + sbs, ns2, E2, p->min_obs_per_base, p->running_stat_width, 0, cpts2);
+        if (nc2 < 0) { status = WDX_FAIL_UNKNOWN; goto done; }
+        if (nc2 == 0) { status = WDX_FAIL_SEGMENT; goto done; }
+        /* compute_base_means(raw_signal[sbs:], valid_cpts): a last boundary beyond the slice (window width
+         * shrunk below the configured one) indexes out of bounds in the Cython loop -> exception -> "unknown" */
+        if (cpts2[nc2 - 1] != n - sbs) { status = WDX_FAIL_UNKNOWN; goto done; }
+        int64_t nseg2 = nc2 - 1;
+        wdx_oracle_new_means(x + sbs, cpts2, nseg2, ev2);
+        /* normalize_wrt(barcode_event_means, adapter_event_means, segmentation.normalization), sig_proc.py:478-480 */
+        double shift, scale;
+        if (p->seg_norm == 1) { shift = np_mean_f64(ev, nseg); scale = np_std_f64(ev, nseg, tmp); }
+        else if (p->seg_norm == 2) {
+            shift = median_f64(ev, nseg, tmp);
+            for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(ev[i] - shift);
+            scale = median_f64(tmp2, nseg, tmp);
+        } else { status = WDX_FAIL_UNKNOWN; goto done; } /* "none" is not a normalize_wrt method: ValueError */
+        /* stats from the ADAPTER arrays, sig_proc.py:486-494 */
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = (double)(cpts[i + 1] - cpts[i]);
+        double dt_med = median_f64(tmp2, nseg, tmp);
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(tmp2[i] - dt_med);
+        double dt_mad = median_f64(tmp2, nseg, tmp);
+        double ev_mean = np_mean_f64(ev, nseg), ev_std = np_std_f64(ev, nseg, tmp);
+        double ev_med = median_f64(ev, nseg, tmp);
+        for (int64_t i = 0; i < nseg; i++) tmp2[i] = fabs(ev[i] - ev_med);
+        double ev_mad = median_f64(tmp2, nseg, tmp);
+        stats[0] = dt_med; stats[1] = dt_mad; stats[2] = ev_mean; stats[3] = ev_std; stats[4] = ev_med; stats[5] = ev_mad;
+        idx[0] = (int32_t)qs; idx[1] = (int32_t)qe; idx[2] = (int32_t)sbs;
+        if (qs > rp->ub_start || qe < rp->lb_end || qe > rp->ub_end) { status = WDX_FAIL_CONSENSUS; goto done; }
+        /* tail: the last barcode_num_events[1] of the normalised barcode event means; fewer -> the np.pad call
+         * subtracts an int from a tuple -> TypeError -> "unknown" */
+        if (nseg2 < Kk) { status = WDX_FAIL_UNKNOWN; goto done; }
+        for (int64_t i = 0; i < Kk; i++) {
+            fpt[i] = (ev2[nseg2 - Kk + i] - shift) / scale;
+            dwell[i] = cpts2[nseg2 - Kk + i + 1] - cpts2[nseg2 - Kk + i];
+        }
+    }
+done:
+    a_free(sig);
+    a_free(x);
+    a_free(cpts);
+    a_free(ev);
+    return status;
+}
+
+int wdx_oracle_fingerprint_refine_batch(const float *sig, int64_t n_reads, int64_t stride, const int32_t *a_start,
+                                        const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
+                                        const wdx_refine_params *rp, double *fpt, int64_t *dwell, double *stats,
+                                        int32_t *idx, int32_t *status) {
+    int64_t K = rp->barcode_keep_events;
+    for (int64_t r = 0; r < n_reads; r++) {
+        size_t mark_ = a_enter((int64_t)a_end[r] - a_start[r] + 2 * (int64_t)p->padding);
+        status[r] = fingerprint_refine_one_impl(sig + r * stride, stride, a_start[r], a_end[r], ok ? ok[r] : 1, p, rp,
+                                                fpt + r * K, dwell + r * K, stats + r * 6, idx + r * 3);
+        a_leave(mark_);
+    }
+    return 0;
+}
+
 /* batch driver mirroring the per-read loop at file_proc.py:418-428 */
 int wdx_oracle_fingerprint_batch(const float *sig, int64_t n_reads, int64_t stride,
                                  const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,

@@ -22,6 +22,7 @@ FAIL_REASONS = {
     3: "event segmentation failed",
     4: "segment normalization failed",
     5: "unknown",
+    6: "consensus query outlier",
 }
 
 
@@ -65,6 +66,42 @@ class SegParams:
         )
 
 
+class RefineParamsC(C.Structure):
+    _fields_ = [
+        ("query", C.c_void_p),
+        ("n_query", C.c_int32),
+        ("subseq_norm", C.c_int32),
+        ("penalty", C.c_double),
+        ("psi", C.c_int32 * 4),
+        ("ub_start", C.c_int32),
+        ("lb_end", C.c_int32),
+        ("ub_end", C.c_int32),
+        ("barcode_segm_events", C.c_int32),
+        ("barcode_keep_events", C.c_int32),
+    ]
+
+
+@dataclass
+class RefineParams:
+    """segmentation.consensus_* knobs (config/sig_proc.py:57-66; values of the tRNA config) + the consensus query."""
+
+    query: np.ndarray = None
+    subseq_norm: str = "mean"
+    penalty: float = 1.5
+    psi: tuple = (5, 0, 40, 0)
+    ub_start: int = 18
+    lb_end: int = 69
+    ub_end: int = 97
+    barcode_segm_events: int = 25
+    barcode_keep_events: int = 25
+
+    def to_c(self):
+        self._q = np.ascontiguousarray(self.query, dtype=np.float64)
+        return RefineParamsC(self._q.ctypes.data, self._q.size, NORM_CODES[self.subseq_norm], float(self.penalty),
+                             (C.c_int32 * 4)(*[int(v) for v in self.psi]), self.ub_start, self.lb_end, self.ub_end,
+                             self.barcode_segm_events, self.barcode_keep_events)
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "wdx_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -99,6 +136,10 @@ def lib():
         L.wdx_oracle_nanmedian_mad_f32.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.wdx_oracle_normalize_wrt.restype = C.c_int
         L.wdx_oracle_normalize_wrt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.wdx_oracle_subseq_match.restype = C.c_int
+        L.wdx_oracle_subseq_match.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.wdx_oracle_fingerprint_refine_batch.restype = C.c_int
+        L.wdx_oracle_fingerprint_refine_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, P(SegParamsC), P(RefineParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wdx_oracle_fingerprint_batch.restype = C.c_int
         L.wdx_oracle_fingerprint_batch.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, P(SegParamsC), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.wdx_oracle_fingerprint_packed.restype = C.c_int
@@ -210,6 +251,36 @@ def fingerprint_batch(sig, a_start, a_end, params: SegParams, ok=None):
     pc = params.to_c()
     lib().wdx_oracle_fingerprint_batch(_p(sig), n, stride, _p(a_start), _p(a_end), None if okp is None else _p(okp), C.byref(pc), _p(fpt), _p(dwell), _p(stats), _p(status))
     return fpt, dwell, stats, status
+
+
+def subseq_match(query, series, penalty=1.5, psi=(5, 0, 40, 0)):
+    """(start, end) = SubsequenceAlignment(...).best_match().segment as sig_proc.py:287-306 obtains it."""
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    s = np.ascontiguousarray(series, dtype=np.float64)
+    st, en = C.c_int64(0), C.c_int64(0)
+    if lib().wdx_oracle_subseq_match(_p(q), q.size, _p(s), s.size, float(penalty), int(psi[0]), int(psi[2]),
+                                     C.byref(st), C.byref(en)):
+        raise ValueError("empty query or series")
+    return st.value, en.value
+
+
+def fingerprint_refine_batch(sig, a_start, a_end, params: SegParams, rp: RefineParams, ok=None):
+    """consensus-refinement branch -> (fpt (n,K), dwell (n,K), stats (n,6), idx (n,3), status)"""
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    n, stride = sig.shape
+    K = rp.barcode_keep_events
+    a_start = np.ascontiguousarray(a_start, dtype=np.int32)
+    a_end = np.ascontiguousarray(a_end, dtype=np.int32)
+    okp = None if ok is None else np.ascontiguousarray(ok, dtype=np.uint8)
+    fpt = np.full((n, K), np.nan)
+    dwell = np.zeros((n, K), dtype=np.int64)
+    stats = np.full((n, 6), np.nan)
+    idx = np.full((n, 3), -1, dtype=np.int32)
+    status = np.zeros(n, dtype=np.int32)
+    pc, rc = params.to_c(), rp.to_c()
+    lib().wdx_oracle_fingerprint_refine_batch(_p(sig), n, stride, _p(a_start), _p(a_end), None if okp is None else _p(okp),
+                                              C.byref(pc), C.byref(rc), _p(fpt), _p(dwell), _p(stats), _p(idx), _p(status))
+    return fpt, dwell, stats, idx, status
 
 
 def fingerprint_packed(sig, off, a_start, a_end, params: SegParams):

@@ -1,0 +1,121 @@
+"""N3 consensus-guided barcode refinement on the device (wdx_fingerprint_refine_batch) against the reference-derived
+fixture g8 and, on many more reads, against the oracle.  Bit-exact: status, query start/end, barcode start, dwell,
+float64 fingerprints and stats."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+
+from oracle import wdx_oracle as orc
+from test_oracle_refine import params_from
+from warpdemux_amd import sig_proc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_refinement_golden_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_refine.npz"))
+    seen = set()
+    for k in range(int(g["n"])):
+        seg, ref = params_from(g, k)
+        row = g[f"row_{k}"]
+        a_s, a_e = (int(v) for v in g[f"args_{k}"])
+        fb = sig_proc.fingerprint_refine_batch(row.reshape(1, -1), [a_s], [a_e], sig_proc.SegParams(**seg),
+                                               sig_proc.RefineParams(query=g["consensus"], **ref))
+        st, tag = int(g[f"status_{k}"]), str(g[f"tag_{k}"])
+        assert int(fb.status[0]) == st, f"case {k} ({tag}): status {fb.status[0]} != {st}"
+        seen.add(st)
+        if st in (0, 6):
+            assert _same(fb.stats[0], g[f"stats_{k}"]), f"case {k} ({tag}) stats"
+            assert _same(fb.refine_idx[0], g[f"idx_{k}"]), f"case {k} ({tag}) query start/end, barcode start"
+        if st == 0:
+            assert _same(fb.fpt[0], g[f"fpt_{k}"]), f"case {k} ({tag}) fpt"
+            assert _same(fb.dwell[0], g[f"dwell_{k}"]), f"case {k} ({tag}) dwell"
+        else:
+            assert np.isnan(fb.fpt).all() and (fb.dwell == 0).all()
+    assert {0, 3, 5, 6} <= seen
+
+
+def _reads(consensus, n, seed):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for i in range(n):
+        n_lead = int(rng.integers(2, 34))
+        emb = rng.random() > 0.15
+        lv = list(rng.normal(0, 1, n_lead)) + list(consensus if emb else rng.normal(0, 1, consensus.size)) + list(rng.normal(0, 1, 30))
+        lv = np.array(lv) * 12.0 + 85.0
+        dw = rng.integers(12, 60, lv.size)
+        x = np.repeat(lv, dw) + rng.normal(0, rng.uniform(0.8, 3.0), int(dw.sum()))
+        rows.append(x.astype(np.float32))
+    stride = max(r.size for r in rows)
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, : r.size] = r
+    a_s = np.full(n, 100, dtype=np.int32)
+    a_e = np.array([r.size - 100 for r in rows], dtype=np.int32)
+    return mb, a_s, a_e
+
+
+@pytest.mark.parametrize("norms", [("mean", "mean"), ("median", "median"), ("mean", "none")])
+def test_refinement_minibatch_vs_oracle(golden_dir, norms):
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]
+    mb, a_s, a_e = _reads(consensus, 96, 11)
+    ok = np.ones(96, dtype=np.uint8)
+    ok[5] = 0
+    mb[7, 2000:2004] = np.nan          # NaN in the window
+    a_e[9] = a_s[9] + 900              # far too short
+    seg = dict(min_obs_per_base=9, running_stat_width=18, num_events=120, seg_norm=norms[0])
+    ref = dict(subseq_norm=norms[1], barcode_segm_events=25, barcode_keep_events=25)
+    fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=25, **seg),
+                                           sig_proc.RefineParams(query=consensus, **ref), success=ok)
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=25, **seg),
+                                                                  orc.RefineParams(query=consensus, **ref), ok=ok)
+    assert np.array_equal(fb.status, status), (fb.status, status)
+    assert (status == 6).sum() >= 3 and status[5] == 1
+    if norms[1] != "none":   # un-normalised event means (pA) do not match the z-scored consensus: all outliers
+        assert (status == 0).sum() >= 25
+    good, rep = status == 0, (status == 0) | (status == 6)
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good])
+    assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep])
+    assert np.isnan(fb.fpt[~good]).all()
+
+
+def test_refinement_through_the_reference_shaped_api(golden_dir):
+    """detect_results_to_fpt(_batch) with segmentation.consensus_refinement = True: the fields the reference's
+    ReadResult carries in this mode (sig_proc.py:590-605, 497-512)."""
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]
+    mb, a_s, a_e = _reads(consensus, 12, 5)
+    spc = NS(sig_extract=NS(padding=100, normalization="none"), core=NS(sig_norm_outlier_thresh=5.0),
+             segmentation=NS(min_obs_per_base=9, running_stat_width=18, num_events=120, accept_less_cpts=False,
+                             normalization="mean", barcode_num_events=[25, 25], consensus_refinement=True,
+                             consensus_model="rna004_130bps_v1_0", consensus_subseq_match_normalization="mean",
+                             consensus_subseq_match_penalty=1.5, consensus_subseq_match_psi=[5, 0, 40, 0],
+                             consensus_subseq_match_ub_start=18, consensus_subseq_match_lb_end=69,
+                             consensus_subseq_match_ub_end=97, refinement_optimal_cpts=False))
+    drs = [sig_proc.DetectResults(True, "", int(a_s[i]), int(a_e[i])) for i in range(12)]
+    res = sig_proc.detect_results_to_fpt_batch(mb, spc, drs, consensus_query=consensus)
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(
+        mb, a_s, a_e, orc.SegParams(min_obs_per_base=9, running_stat_width=18, num_events=120),
+        orc.RefineParams(query=consensus))
+    assert {0, 6} <= set(status.tolist())
+    for i, r in enumerate(res):
+        assert r.success == (status[i] == 0)
+        if status[i] in (0, 6):
+            assert (r.seg_cons_query_start, r.seg_cons_query_end, r.sig_barcode_start) == tuple(int(v) for v in idx[i])
+            assert r.adapter_event_mean == stats[i, 2]
+        if status[i] == 0:
+            assert _same(r.barcode_fpt, fpt[i]) and _same(r.dwell_times, dwell[i])
+        if status[i] == 6:
+            assert r.fail_reason == "consensus query outlier" and r.barcode_fpt.size == 0
+    one = sig_proc.detect_results_to_fpt(mb[0], spc, drs[0], consensus)
+    assert _same(one.barcode_fpt, res[0].barcode_fpt)
+    with pytest.raises(ValueError, match="consensus_model must be specified"):
+        sig_proc.detect_results_to_fpt_batch(mb, spc, drs)
+    spc.segmentation.barcode_num_events = 25
+    with pytest.raises(ValueError, match="use a tuple instead"):
+        sig_proc.detect_results_to_fpt_batch(mb, spc, drs, consensus_query=consensus)

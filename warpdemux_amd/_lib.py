@@ -36,7 +36,7 @@ EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
     "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_unique_id", "wdx_comm_init",
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_live_tick", "wdx_svm_set_model",
+    "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
@@ -58,6 +58,23 @@ class SegParamsC(C.Structure):
         ("barcode_num_events", C.c_int32),
         ("clip_bounds_f64", C.c_int32),
         ("outlier_thresh_f64", C.c_double),
+    ]
+
+
+class RefineParamsC(C.Structure):
+    """wdx_refine_params (include/wdx.h)"""
+
+    _fields_ = [
+        ("query", C.c_void_p),
+        ("n_query", C.c_int32),
+        ("subseq_norm", C.c_int32),
+        ("penalty", C.c_double),
+        ("psi", C.c_int32 * 4),
+        ("ub_start", C.c_int32),
+        ("lb_end", C.c_int32),
+        ("ub_end", C.c_int32),
+        ("barcode_segm_events", C.c_int32),
+        ("barcode_keep_events", C.c_int32),
     ]
 
 
@@ -165,6 +182,8 @@ def load():
         L.wdx_dtw_matrix_dev.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_fingerprint_batch.restype = C.c_int
         L.wdx_fingerprint_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
+        L.wdx_fingerprint_refine_batch.restype = C.c_int
+        L.wdx_fingerprint_refine_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), P(RefineParamsC), vp, vp, vp, vp, vp]
         L.wdx_svm_set_model.restype = C.c_int
         L.wdx_svm_set_model.argtypes = [vp, P(SvmModelC)]
         L.wdx_svm_predict_dev.restype = C.c_int

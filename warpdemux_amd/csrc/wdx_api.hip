@@ -514,11 +514,18 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
     return rc;
 }
 
-int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
-                          const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
-                          const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
-                          int32_t *status) {
+static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                                  const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                                  const wdx_seg_params *p_in, const wdx_refine_params *rp, double *fpt, int64_t *dwell,
+                                  double *stats, int32_t *refine_idx, int32_t *status) {
     WDX_ENTER(ctx);
+    if (!p_in || (rp && (!rp->query || !refine_idx))) {
+        set_error("fingerprint_batch: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    wdx_seg_params pv = *p_in;
+    if (rp) pv.barcode_num_events = rp->barcode_keep_events;  // K of the outputs
+    const wdx_seg_params *p = &pv;
     if (n_reads < 0 || stride < 0 || !p ||
         (n_reads > 0 && (!sig || !a_start || !a_end || !fpt || !dwell || !stats || !status))) {
         set_error("fingerprint_batch: bad arguments");
@@ -556,6 +563,25 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
     if ((rc = ctx->out2.ensure((size_t)n_reads * 6 * 8))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    RefineDev *rf = nullptr;
+    struct RfGuard {
+        RefineDev *&r;
+        ~RfGuard() { free_refine_dev(r); }
+    } rf_guard{rf};
+    if (rp) {
+        // [query doubles | idx int32 (n,3)] on the device; idx starts as -1 (reads that fail before the match)
+        const size_t qb = ((size_t)rp->n_query * 8 + 15) / 16 * 16;
+        if (rp->n_query < 1) {
+            set_error("consensus refinement: empty query");
+            return WDX_ERR_INVALID;
+        }
+        if ((rc = ctx->ref_buf.ensure(qb + (size_t)n_reads * 12))) return rc;
+        WDX_HIP_TRY(hipMemcpyAsync(ctx->ref_buf.p, rp->query, (size_t)rp->n_query * 8, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemsetAsync((unsigned char *)ctx->ref_buf.p + qb, 0xff, (size_t)n_reads * 12, s));
+        if ((rc = fill_refine_dev(*rp, (const double *)ctx->ref_buf.p, (int32_t *)((unsigned char *)ctx->ref_buf.p + qb),
+                                  &rf)))
+            return rc;
+    }
     // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
     // file_proc.py:244-260; the kernels never read outside [start, stop))
     if (col1 > col0)
@@ -573,15 +599,40 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p,
                                      (double *)ctx->out0.p, (int64_t *)ctx->out1.p,
                                      (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p,
-                                     ctx->knobs, &t.n_launches)))
+                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, rf)))
             return rc;
     }
     WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipMemcpyAsync(dwell, ctx->out1.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipMemcpyAsync(stats, ctx->out2.p, (size_t)n_reads * 48, hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipMemcpyAsync(status, ctx->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+    if (rp) {
+        const size_t qb = ((size_t)rp->n_query * 8 + 15) / 16 * 16;
+        WDX_HIP_TRY(hipMemcpyAsync(refine_idx, (unsigned char *)ctx->ref_buf.p + qb, (size_t)n_reads * 12,
+                                   hipMemcpyDeviceToHost, s));
+    }
     WDX_HIP_TRY(hipStreamSynchronize(s));
     return WDX_SUCCESS;
+}
+
+int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                          const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                          const wdx_seg_params *p, double *fpt, int64_t *dwell, double *stats,
+                          int32_t *status) {
+    return fingerprint_batch_impl(ctx, sig, n_reads, stride, a_start, a_end, ok, p, nullptr, fpt, dwell, stats, nullptr,
+                                  status);
+}
+
+int wdx_fingerprint_refine_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t stride,
+                                 const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
+                                 const wdx_seg_params *p, const wdx_refine_params *rp, double *fpt, int64_t *dwell,
+                                 double *stats, int32_t *refine_idx, int32_t *status) {
+    if (!rp) {
+        set_error("fingerprint_refine_batch: null refinement parameters");
+        return WDX_ERR_INVALID;
+    }
+    return fingerprint_batch_impl(ctx, sig, n_reads, stride, a_start, a_end, ok, p, rp, fpt, dwell, stats, refine_idx,
+                                  status);
 }
 
 int64_t wdx_demux_workspace_bytes(int64_t n_reads, int32_t K) {

@@ -93,6 +93,10 @@ int launch_argmin(const float *D, int64_t n, int64_t m, int32_t *out, hipStream_
 int launch_count_calls(int32_t *call, const int32_t *status /*nullable*/, int64_t n, int64_t m,
                        int64_t *counts /*nullable*/, hipStream_t stream);
 
+struct RefineDev;  // wdx_fingerprint.hip: device-side view of wdx_refine_params
+int fill_refine_dev(const wdx_refine_params &rp, const double *d_query, int32_t *d_idx, struct RefineDev **out);
+void free_refine_dev(struct RefineDev *rf);
+
 // ---- fingerprint (wdx_fingerprint.hip) ---------------------------------------------------------
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
@@ -100,7 +104,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
                        const Knobs &knobs, int64_t *n_launches = nullptr, long long *d_prof = nullptr,
-                       int64_t prof_reads = 0, int stop_phase = 0);
+                       int64_t prof_reads = 0, int stop_phase = 0, const struct RefineDev *rf = nullptr);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------

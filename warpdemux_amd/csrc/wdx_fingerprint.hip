@@ -34,6 +34,19 @@ constexpr int kSegCap = kMaxEvents + 1;
 
 enum : unsigned char { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_DROPPED = 3, ST_SELECTED = 4 };
 
+// consensus-guided refinement (sig_proc.py:257-378, 452-521); query == nullptr: plain branch
+struct RefineDev {
+    const double *query;   // consensus signal, DEVICE pointer
+    int nq, norm;          // its length; consensus_subseq_match_normalization (WDX_NORM_*)
+    double pen;            // consensus_subseq_match_penalty (un-squared)
+    int psi1b, psi2b;      // relaxations at the beginning of the query / of the series
+    int ub_start, lb_end, ub_end;
+    int E2;                // barcode_num_events[0]
+    int32_t *idx;          // (n_reads, 3) seg_cons_query_start, seg_cons_query_end, sig_barcode_start; nullable
+};
+constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
+constexpr int kRefineMaxSeries = 128;
+
 struct FpArgs {
     const float *sig;
     const int64_t *row_off;
@@ -53,6 +66,7 @@ struct FpArgs {
     long long *prof;     // diagnostic build only: 32 int64 per read (cycle stamps etc.)
     int64_t prof_reads;
     int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
+    RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
 };
 
 struct alignas(8) FpShared {
@@ -441,6 +455,368 @@ __device__ void block_small_median(const double *a, int n, FpShared &sh, int slo
     __syncthreads();
 }
 
+// find_peaks(scores[0..ns), distance=d_eff) -> the E highest -> boundaries 0, peaks + W, n_end
+// -> event means over sig (sig_proc.py:176-198, segmentation.py:48-74).  Used for the adapter and, in the
+// consensus-refinement branch, once more for the barcode tail of the same score curve.  All threads call;
+// returns a block-uniform WDX_READ_* status; on success cpts[0..nseg] and ev[0..nseg).
+template <int BLOCK>
+__device__ int fp_segment(const double *scores, unsigned char *state, const int ns, const int d_eff, const int W,
+                          const int E, const bool accept_less, const float *sig, const int n_end, int *cpts, double *ev,
+                          unsigned *hist, FpShared &sh, int &nseg, int &nms_iters) {
+    const int tid = threadIdx.x;
+    // ---- P3: find_peaks(scores, distance=d_eff) (SURVEY.md App. B) ----------------------------------
+    for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
+    __syncthreads();
+    for (int i = 1 + tid; i < ns - 1; i += BLOCK) {
+        const double s = scores[i];
+        if (scores[i - 1] < s) {
+            int ia = i + 1;
+            while (ia < ns - 1 && scores[ia] == s) ++ia;
+            if (scores[ia] < s) state[(i + ia - 1) / 2] = ST_UNDECIDED;
+        }
+    }
+    __syncthreads();
+    {
+        // greedy suppression by priority == fixed point of: a peak is KEPT once every higher-priority
+        // peak closer than d_eff is DROPPED, and DROPPED as soon as one of them is KEPT.
+        // priority order: score, ties -> larger position first (stable argsort read from the end).
+        const int D1 = d_eff - 1;
+        for (;;) {
+            int pending = 0;
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] != ST_UNDECIDED) continue;
+                const double s = scores[i];
+                bool kept_near = false, wait = false;
+                const int lo = max(0, i - D1), hi = min(ns - 1, i + D1);
+                for (int q = lo; q <= hi; ++q) {
+                    if (q == i) continue;
+                    const unsigned char st = state[q];
+                    if (st == ST_KEPT) kept_near = true;
+                    else if (st == ST_UNDECIDED) {
+                        const double sq = scores[q];
+                        if (sq > s || (sq == s && q > i)) wait = true;
+                    }
+                }
+                if (kept_near) state[i] = ST_DROPPED;
+                else if (!wait) state[i] = ST_KEPT;
+                else pending = 1;
+            }
+            ++nms_iters;
+            if (!__syncthreads_or(pending)) break;
+        }
+    }
+
+    // ---- P4: keep the E highest peaks (sig_proc.py:185-188) -----------------------------------------
+    int nsel;
+    {
+        unsigned long long kmin = ~0ull, kmax = 0;
+        unsigned cnt = 0;
+        for (int i = tid; i < ns; i += BLOCK) {
+            if (state[i] == ST_KEPT) {
+                unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+                cnt++;
+            }
+        }
+        unsigned long long gmin, gmax;
+        unsigned nk;
+        block_minmax64_count<BLOCK>(kmin, kmax, cnt, sh, gmin, gmax, nk);
+        if ((int)nk < E && !accept_less) return WDX_READ_FAIL_SEGMENT;
+        if (nk == 0) return WDX_READ_FAIL_UNKNOWN;  // valid_cpts[0] on an empty array
+        if ((int)nk <= E) {
+            nsel = (int)nk;
+            __syncthreads();
+            for (int i = tid; i < ns; i += BLOCK)
+                if (state[i] == ST_KEPT) state[i] = ST_SELECTED;
+        } else {
+            nsel = E;
+            auto keyfn = [&](int i, unsigned long long &key) {
+                key = (unsigned long long)__double_as_longlong(scores[i]);
+                return state[i] == ST_KEPT;
+            };
+            const unsigned long long T =
+                block_select_u64<BLOCK>(keyfn, ns, nk - (unsigned)E, gmin, gmax, hist, sh);
+            unsigned gt = 0, eq = 0, z0 = 0xffffffffu;
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] == ST_KEPT) {
+                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                    gt += k > T;
+                    eq += k == T;
+                }
+            }
+            unsigned ggt, geq, dmy;
+            block_minmax_count<BLOCK>(z0, gt, eq, sh, dmy, dmy, geq);  // geq = sum(eq)
+            block_minmax_count<BLOCK>(z0, 0u, gt, sh, dmy, dmy, ggt);  // ggt = sum(gt)
+            const unsigned need = (unsigned)E - ggt;  // 1 <= need <= geq
+            __syncthreads();
+            for (int i = tid; i < ns; i += BLOCK) {
+                if (state[i] == ST_KEPT) {
+                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
+                    if (k > T || (k == T && need == geq)) state[i] = ST_SELECTED;
+                }
+            }
+            __syncthreads();
+            if (need != geq && tid == 0) {
+                // exact score ties at the cut: the stable order keeps the LAST `need` of them
+                unsigned left = need;
+                for (int i = ns - 1; i >= 0 && left; --i) {
+                    if (state[i] == ST_KEPT &&
+                        (unsigned long long)__double_as_longlong(scores[i]) == T) {
+                        state[i] = ST_SELECTED;
+                        --left;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- P5: boundaries 0, peaks+W (ascending), n  (sig_proc.py:188-196) -----------------------------
+    {
+        const int chunk = (ns + BLOCK - 1) / BLOCK;
+        const int c0 = tid * chunk, c1 = min(ns, c0 + chunk);
+        int local = 0;
+        for (int i = c0; i < c1; ++i) local += state[i] == ST_SELECTED;
+        // block exclusive scan of `local`
+        int incl = local;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) sh.red_a[wave] = (unsigned)incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += (int)sh.red_a[k];
+        int o = base + incl - local;
+        for (int i = c0; i < c1; ++i)
+            if (state[i] == ST_SELECTED) cpts[1 + o++] = i + W;
+        if (tid == 0) {
+            cpts[0] = 0;
+            cpts[nsel + 1] = n_end;
+        }
+        __syncthreads();
+    }
+    nseg = nsel + 1;
+
+    // ---- P6: event means (_c_segmentation.pyx:41-53), sequential float64 sums ------------------------
+    for (int s = tid; s < nseg; s += BLOCK) {
+        const int b = cpts[s], e = cpts[s + 1];
+        double sum = 0.0;
+        for (int i = b; i < e; ++i) sum += (double)sig[i];
+        ev[s] = sum / (double)(e - b);
+    }
+    __syncthreads();
+
+    return WDX_READ_OK;
+}
+
+// Consensus-guided barcode refinement, everything after the adapter's segmentation (sig_proc.py:287-378,
+// 452-521; oracle: fingerprint_refine_one_impl).  The subsequence match (dtaidistance warping_paths_fast +
+// SubsequenceAlignment.best_match, restated -- parity unpinned) is an anti-diagonal wavefront:
+// thread i owns query row i, front k holds the cells (i, k - i); a cell needs the two previous fronts only, so
+// three fronts of (cost, sqrt(cost)) pairs rotate through LDS, and what the back-trace needs -- argmin of the
+// three predecessors' sqrt'ed costs per cell, first minimum -- is kept as 2-bit codes, 16 per word, one row of
+// words per thread.  scratch: >= 3*(nq+1)*16 + nq*ceil(nseries/16)*4 bytes of LDS (the t-score tile buffers).
+template <int BLOCK>
+__device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *scores, unsigned char *state,
+                               const int ns, const int W, const int n, const float *sig, int *cpts, double *ev,
+                               double *zz, double *tmp, unsigned char *scratch, unsigned *hist, FpShared &sh,
+                               const int nseg) {
+    const int tid = threadIdx.x;
+    const wdx_seg_params &P = A.p;
+    const RefineDev &R = A.rf;
+    const int K = P.barcode_num_events;  // = barcode_num_events[1], set by the host
+    auto finish = [&](int st, bool with_stats) {
+        if (st != WDX_READ_OK) {
+            for (int i = tid; i < K; i += BLOCK) {
+                if (A.fpt) A.fpt[r * K + i] = __builtin_nan("");
+                if (A.dwell) A.dwell[r * K + i] = 0;
+            }
+            if (!with_stats) {
+                if (A.stats && tid < 6) A.stats[r * 6 + tid] = __builtin_nan("");
+                if (R.idx && tid < 3) R.idx[r * 3 + tid] = -1;
+            }
+        }
+        if (tid == 0) A.status[r] = st;
+    };
+    // normalize(series, method, accept_nan=False) inside _get_subseq_match raises on NaN -> "unknown"
+    {
+        int has_nan = 0;
+        for (int s = tid; s < nseg; s += BLOCK) has_nan |= (ev[s] != ev[s]);
+        if (__syncthreads_or(has_nan)) {
+            finish(WDX_READ_FAIL_UNKNOWN, false);
+            return;
+        }
+    }
+    // adapter statistics (sig_proc.py:486-494) and the shift / scale of both normalisations
+    if (tid == 0) sh.mean = np_pairwise_sum_dev(ev, nseg) / (double)nseg;
+    __syncthreads();
+    const double mean = sh.mean;
+    for (int s = tid; s < nseg; s += BLOCK) {
+        const double df = ev[s] - mean;
+        tmp[s] = df * df;
+    }
+    __syncthreads();
+    if (tid == 0) sh.sd = sqrt(np_pairwise_sum_dev(tmp, nseg) / (double)nseg);
+    __syncthreads();
+    const double sd = sh.sd;
+    for (int s = tid; s < nseg; s += BLOCK) tmp[s] = (double)(cpts[s + 1] - cpts[s]);
+    block_small_median<BLOCK>(tmp, nseg, sh, 0);
+    const double dt_med = sh.stat[0];
+    for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(tmp[s] - dt_med);
+    block_small_median<BLOCK>(tmp, nseg, sh, 1);
+    block_small_median<BLOCK>(ev, nseg, sh, 4);
+    const double ev_med = sh.stat[4];
+    for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(ev[s] - ev_med);
+    block_small_median<BLOCK>(tmp, nseg, sh, 5);
+    const double ev_mad = sh.stat[5];
+    const double dt_mad = sh.stat[1];
+    // series of the match: normalize(adapter_event_means, consensus_subseq_match_normalization)
+    {
+        double c0 = 0.0, c1 = 1.0;
+        if (R.norm == WDX_NORM_MEAN) { c0 = mean; c1 = sd; }
+        else if (R.norm == WDX_NORM_MEDIAN) { c0 = ev_med; c1 = ev_mad; }
+        else if (R.norm != WDX_NORM_NONE) { finish(WDX_READ_FAIL_UNKNOWN, false); return; }
+        int bad = 0;
+        for (int s = tid; s < nseg; s += BLOCK) {
+            const double v = R.norm == WDX_NORM_NONE ? ev[s] : (ev[s] - c0) / c1;
+            zz[s] = v;
+            bad |= (v != v);
+        }
+        if (__syncthreads_or(bad)) {  // a constant series (0/0): the library's behaviour on NaN is not restated
+            finish(WDX_READ_FAIL_UNKNOWN, false);
+            return;
+        }
+    }
+    // ---- subsequence DTW of the consensus query against the normalised event means ------------------------
+    const int nq = R.nq, c = nseg, WPR = (c + 15) >> 4;
+    struct DS { double D, S; };
+    DS *F = reinterpret_cast<DS *>(scratch);
+    unsigned *dirw = reinterpret_cast<unsigned *>(F + 3 * (nq + 1));
+    double *lastS = tmp;
+    {
+        const double p2 = R.pen * R.pen, inf = __builtin_huge_val();
+        const double qi = (tid >= 1 && tid <= nq) ? R.query[tid - 1] : 0.0;
+        unsigned acc = 0;
+        for (int k = 0; k <= nq + c; ++k) {
+            if (tid <= nq) {
+                const int i = tid, j = k - i;
+                if (j >= 0 && j <= c) {
+                    DS out;
+                    if (i == 0) {
+                        out.D = j <= R.psi2b ? 0.0 : inf;
+                        out.S = out.D;
+                    } else if (j == 0) {
+                        out.D = i <= R.psi1b ? 0.0 : inf;
+                        out.S = out.D;
+                    } else {
+                        const DS dg = F[((k - 2) % 3) * (nq + 1) + i - 1], up = F[((k - 1) % 3) * (nq + 1) + i - 1],
+                                 lf = F[((k - 1) % 3) * (nq + 1) + i];
+                        double d = qi - zz[j - 1];
+                        d = d * d;
+                        double m = dg.D, t = up.D + p2;
+                        if (t < m) m = t;
+                        t = lf.D + p2;
+                        if (t < m) m = t;
+                        out.D = d + m;
+                        out.S = sqrt(out.D);
+                        unsigned code = 0;
+                        double mv = dg.S;
+                        if (up.S < mv) { mv = up.S; code = 1; }
+                        if (lf.S < mv) code = 2;
+                        acc |= code << (2 * ((j - 1) & 15));
+                        if (((j - 1) & 15) == 15 || j == c) {
+                            dirw[(i - 1) * WPR + ((j - 1) >> 4)] = acc;
+                            acc = 0;
+                        }
+                        if (i == nq) lastS[j - 1] = out.S;
+                    }
+                    F[(k % 3) * (nq + 1) + i] = out;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        int best = 0;
+        double bv = lastS[0] / (double)nq;
+        for (int j = 1; j < c; ++j) {
+            const double v = lastS[j] / (double)nq;
+            if (v < bv) { bv = v; best = j; }
+        }
+        int i = nq, j = best + 1, sj = j;
+        while (i > 0 && j > 0) {
+            sj = j;
+            const unsigned code = (dirw[(i - 1) * WPR + ((j - 1) >> 4)] >> (2 * ((j - 1) & 15))) & 3u;
+            if (code == 0) { --i; --j; }
+            else if (code == 1) --i;
+            else --j;
+        }
+        sh.flag = sj - 1;   // seg_cons_query_start
+        sh.count = best;    // seg_cons_query_end
+    }
+    __syncthreads();
+    const int qs = sh.flag, qe = sh.count;
+    const int sbs = cpts[qe];   // int(np.sum(adapter_dwell_times[:seg_query_end]))
+    __syncthreads();            // cpts is rewritten below
+    // ---- the barcode tail: discrepenacy_curve_to_cpts(adapter_scores[sbs:], E2, config d, config W, False) -----
+    int ns2 = ns - sbs;
+    if (ns2 < 0) ns2 = 0;
+    if (P.min_obs_per_base < 1) {  // scipy: `distance` must be >= 1
+        finish(WDX_READ_FAIL_UNKNOWN, false);
+        return;
+    }
+    int nseg2 = 0, it2 = 0;
+    const int n_end2 = ns2 + 2 * P.running_stat_width;
+    {
+        // a last boundary beyond the slice (window width shrunk below the configured one): the Cython loop of
+        // compute_base_means indexes out of bounds -> exception -> "unknown"; checked BEFORE the means are summed
+        if (n_end2 != n - sbs) {
+            // still "event segmentation failed" when the tail has too few peaks (that return comes first)
+            const int st0 = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2,
+                                              false, sig + sbs, min(n_end2, n - sbs), cpts, zz, hist, sh, nseg2, it2);
+            finish(st0 == WDX_READ_FAIL_SEGMENT ? WDX_READ_FAIL_SEGMENT : WDX_READ_FAIL_UNKNOWN, false);
+            return;
+        }
+        const int st = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2, false,
+                                         sig + sbs, n_end2, cpts, zz, hist, sh, nseg2, it2);
+        if (st != WDX_READ_OK) {
+            finish(st, false);
+            return;
+        }
+    }
+    // normalize_wrt(barcode_event_means, adapter_event_means, segmentation.normalization) (sig_proc.py:139-168)
+    double shift, scale;
+    if (P.seg_norm == WDX_NORM_MEAN) { shift = mean; scale = sd; }
+    else if (P.seg_norm == WDX_NORM_MEDIAN) { shift = ev_med; scale = ev_mad; }
+    else { finish(WDX_READ_FAIL_UNKNOWN, false); return; }  // "none" is not a normalize_wrt method: ValueError
+    if (tid == 0) {
+        if (A.stats) {
+            double *o = A.stats + r * 6;
+            o[0] = dt_med; o[1] = dt_mad; o[2] = mean; o[3] = sd; o[4] = ev_med; o[5] = ev_mad;
+        }
+        if (R.idx) {
+            R.idx[r * 3] = qs; R.idx[r * 3 + 1] = qe; R.idx[r * 3 + 2] = sbs;
+        }
+    }
+    if (qs > R.ub_start || qe < R.lb_end || qe > R.ub_end) {
+        finish(WDX_READ_FAIL_CONSENSUS, true);  // "consensus query outlier": stats and indices are reported
+        return;
+    }
+    if (nseg2 < K) {  // the np.pad call subtracts an int from a tuple -> TypeError -> "unknown"
+        finish(WDX_READ_FAIL_UNKNOWN, false);
+        return;
+    }
+    for (int i = tid; i < K; i += BLOCK) {
+        const int s = nseg2 - K + i;
+        if (A.fpt) A.fpt[r * K + i] = (zz[s] - shift) / scale;
+        if (A.dwell) A.dwell[r * K + i] = (int64_t)(cpts[s + 1] - cpts[s]);
+    }
+    finish(WDX_READ_OK, true);
+}
+
 // ---- the kernel -----------------------------------------------------------------------------------
 
 // PROF = diagnostic instantiation with s_memtime stamps between phases (never used by the product
@@ -642,161 +1018,22 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     }
 
     WDX_STAMP(3);
-    // ---- P3: find_peaks(scores, distance=d_eff) (SURVEY.md App. B) ----------------------------------
-    for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
-    __syncthreads();
-    for (int i = 1 + tid; i < ns - 1; i += BLOCK) {
-        const double s = scores[i];
-        if (scores[i - 1] < s) {
-            int ia = i + 1;
-            while (ia < ns - 1 && scores[ia] == s) ++ia;
-            if (scores[ia] < s) state[(i + ia - 1) / 2] = ST_UNDECIDED;
-        }
-    }
-    __syncthreads();
-    WDX_STAMP(4);
-    int nms_iters = 0;
+    // ---- P3-P6: find_peaks + top-E + boundaries + event means (fp_segment) ----------------------------
+    int nms_iters = 0, nseg = 0;
     {
-        // greedy suppression by priority == fixed point of: a peak is KEPT once every higher-priority
-        // peak closer than d_eff is DROPPED, and DROPPED as soon as one of them is KEPT.
-        // priority order: score, ties -> larger position first (stable argsort read from the end).
-        const int D1 = d_eff - 1;
-        for (;;) {
-            int pending = 0;
-            for (int i = tid; i < ns; i += BLOCK) {
-                if (state[i] != ST_UNDECIDED) continue;
-                const double s = scores[i];
-                bool kept_near = false, wait = false;
-                const int lo = max(0, i - D1), hi = min(ns - 1, i + D1);
-                for (int q = lo; q <= hi; ++q) {
-                    if (q == i) continue;
-                    const unsigned char st = state[q];
-                    if (st == ST_KEPT) kept_near = true;
-                    else if (st == ST_UNDECIDED) {
-                        const double sq = scores[q];
-                        if (sq > s || (sq == s && q > i)) wait = true;
-                    }
-                }
-                if (kept_near) state[i] = ST_DROPPED;
-                else if (!wait) state[i] = ST_KEPT;
-                else pending = 1;
-            }
-            ++nms_iters;
-            if (!__syncthreads_or(pending)) break;
-        }
-    }
-    WDX_STAMP(5);
-
-    // ---- P4: keep the E highest peaks (sig_proc.py:185-188) -----------------------------------------
-    int nsel;
-    {
-        unsigned long long kmin = ~0ull, kmax = 0;
-        unsigned cnt = 0;
-        for (int i = tid; i < ns; i += BLOCK) {
-            if (state[i] == ST_KEPT) {
-                unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
-                kmin = k < kmin ? k : kmin;
-                kmax = k > kmax ? k : kmax;
-                cnt++;
-            }
-        }
-        unsigned long long gmin, gmax;
-        unsigned nk;
-        block_minmax64_count<BLOCK>(kmin, kmax, cnt, sh, gmin, gmax, nk);
-        if ((int)nk < E && !P.accept_less_cpts) {
-            finish(WDX_READ_FAIL_SEGMENT);
+        const int st = fp_segment<BLOCK>(scores, state, ns, d_eff, W, E, P.accept_less_cpts != 0, sig, n, cpts, ev,
+                                         hist, sh, nseg, nms_iters);
+        if (st != WDX_READ_OK) {
+            finish(st);
             return;
         }
-        if (nk == 0) {
-            finish(WDX_READ_FAIL_UNKNOWN);  // valid_cpts[0] on an empty array
-            return;
-        }
-        if ((int)nk <= E) {
-            nsel = (int)nk;
-            __syncthreads();
-            for (int i = tid; i < ns; i += BLOCK)
-                if (state[i] == ST_KEPT) state[i] = ST_SELECTED;
-        } else {
-            nsel = E;
-            auto keyfn = [&](int i, unsigned long long &key) {
-                key = (unsigned long long)__double_as_longlong(scores[i]);
-                return state[i] == ST_KEPT;
-            };
-            const unsigned long long T =
-                block_select_u64<BLOCK>(keyfn, ns, nk - (unsigned)E, gmin, gmax, hist, sh);
-            unsigned gt = 0, eq = 0, z0 = 0xffffffffu;
-            for (int i = tid; i < ns; i += BLOCK) {
-                if (state[i] == ST_KEPT) {
-                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
-                    gt += k > T;
-                    eq += k == T;
-                }
-            }
-            unsigned ggt, geq, dmy;
-            block_minmax_count<BLOCK>(z0, gt, eq, sh, dmy, dmy, geq);  // geq = sum(eq)
-            block_minmax_count<BLOCK>(z0, 0u, gt, sh, dmy, dmy, ggt);  // ggt = sum(gt)
-            const unsigned need = (unsigned)E - ggt;  // 1 <= need <= geq
-            __syncthreads();
-            for (int i = tid; i < ns; i += BLOCK) {
-                if (state[i] == ST_KEPT) {
-                    unsigned long long k = (unsigned long long)__double_as_longlong(scores[i]);
-                    if (k > T || (k == T && need == geq)) state[i] = ST_SELECTED;
-                }
-            }
-            __syncthreads();
-            if (need != geq && tid == 0) {
-                // exact score ties at the cut: the stable order keeps the LAST `need` of them
-                unsigned left = need;
-                for (int i = ns - 1; i >= 0 && left; --i) {
-                    if (state[i] == ST_KEPT &&
-                        (unsigned long long)__double_as_longlong(scores[i]) == T) {
-                        state[i] = ST_SELECTED;
-                        --left;
-                    }
-                }
-            }
-        }
-        __syncthreads();
     }
-
-    WDX_STAMP(6);
-    // ---- P5: boundaries 0, peaks+W (ascending), n  (sig_proc.py:188-196) -----------------------------
-    {
-        const int chunk = (ns + BLOCK - 1) / BLOCK;
-        const int c0 = tid * chunk, c1 = min(ns, c0 + chunk);
-        int local = 0;
-        for (int i = c0; i < c1; ++i) local += state[i] == ST_SELECTED;
-        // block exclusive scan of `local`
-        int incl = local;
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) sh.red_a[wave] = (unsigned)incl;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < wave; ++k) base += (int)sh.red_a[k];
-        int o = base + incl - local;
-        for (int i = c0; i < c1; ++i)
-            if (state[i] == ST_SELECTED) cpts[1 + o++] = i + W;
-        if (tid == 0) {
-            cpts[0] = 0;
-            cpts[nsel + 1] = n;
-        }
-        __syncthreads();
-    }
-    const int nseg = nsel + 1;
-
     WDX_STAMP(7);
-    // ---- P6: event means (_c_segmentation.pyx:41-53), sequential float64 sums ------------------------
-    for (int s = tid; s < nseg; s += BLOCK) {
-        const int b = cpts[s], e = cpts[s + 1];
-        double sum = 0.0;
-        for (int i = b; i < e; ++i) sum += (double)sig[i];
-        ev[s] = sum / (double)(e - b);
+    if (A.rf.query) {
+        fp_refine_tail<BLOCK>(A, r, scores, state, ns, W, n, sig, cpts, ev, zz, tmp, reinterpret_cast<unsigned char *>(Mt),
+                              hist, sh, nseg);
+        return;
     }
-    __syncthreads();
 
     WDX_STAMP(8);
     // ---- P7: normalise, stats, tail (sig_proc.py:546-605) --------------------------------------------
@@ -939,6 +1176,22 @@ static int launch_fp_list(const FpArgs &A, size_t lds, const unsigned *count, co
     return WDX_SUCCESS;
 }
 
+int fill_refine_dev(const wdx_refine_params &rp, const double *d_query, int32_t *d_idx, RefineDev **out) {
+    if (rp.subseq_norm != WDX_NORM_NONE && rp.subseq_norm != WDX_NORM_MEAN && rp.subseq_norm != WDX_NORM_MEDIAN) {
+        set_error("Normalization method %d not recognized.", (int)rp.subseq_norm);
+        return WDX_ERR_INVALID;
+    }
+    if (rp.penalty != rp.penalty || rp.penalty < 0) {
+        set_error("consensus refinement: penalty must be >= 0");
+        return WDX_ERR_INVALID;
+    }
+    RefineDev *r = new RefineDev{d_query, rp.n_query, rp.subseq_norm, rp.penalty, rp.psi[0], rp.psi[2],
+                                 rp.ub_start, rp.lb_end, rp.ub_end, rp.barcode_segm_events, d_idx};
+    *out = r;
+    return WDX_SUCCESS;
+}
+void free_refine_dev(RefineDev *rf) { delete rf; }
+
 int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 8 * (n_reads > 0 ? n_reads : 0); }
 
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
@@ -946,7 +1199,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws, const Knobs &knobs, int64_t *n_launches,
-                       long long *d_prof, int64_t prof_reads, int stop_phase) {
+                       long long *d_prof, int64_t prof_reads, int stop_phase, const RefineDev *rf) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (n_reads > 0x7fffffffLL) {
         set_error("at most 2^31-1 reads per call");
@@ -973,7 +1226,19 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, RefineDev{}};
+    if (rf) {
+        if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
+            set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,
+                      kRefineMaxSeries);
+            return WDX_ERR_UNSUPPORTED;
+        }
+        if (rf->E2 < 1 || rf->E2 > kMaxEvents || rf->psi1b < 0 || rf->psi2b < 0) {
+            set_error("consensus refinement: barcode_num_events[0] must be in [1, %d], psi >= 0", kMaxEvents);
+            return WDX_ERR_INVALID;
+        }
+        A.rf = *rf;
+    }
     const size_t lds = fp_lds_bytes(cap);
     if (lds > 160 * 1024) {
         set_error("fingerprint LDS carve-up (%zu B) exceeds 160 KiB", lds);
@@ -988,7 +1253,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
                          p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
-                         !knobs.exact_path;
+                         !knobs.exact_path && !rf;
     if (fast_ok) {
         // samples per thread: the smaller instantiation when the longest adapter window allows it;
         // windows beyond 6144 samples take the slow path

@@ -5,8 +5,10 @@ minibatch (file_proc.py:418-428).  Here the whole minibatch goes to the HIP engi
 (`detect_results_to_fpt_batch`), and thin shims rebuild per-read `ReadResult` objects with the
 reference's field names and fail-reason strings so the callers' savers see the same records.
 
-Only the non-refinement branch is implemented (``segmentation.consensus_refinement = false`` in
-the shipped RNA004 config); asking for refinement raises NotImplementedError.
+Both branches of the reference are covered: the plain one (``segmentation.consensus_refinement = false``, the
+shipped RNA004 config) and the consensus-guided barcode refinement of the tRNA models (sig_proc.py:257-378,
+452-521; `RefineParams`, `fingerprint_refine_batch`).  ``refinement_optimal_cpts`` (ruptures KernelCPD, false
+in every shipped config) is not offered.
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ FAIL_REASONS = {
     3: "event segmentation failed",
     4: "segment normalization failed: Signal contains NaN values.",
     5: "unknown",
+    6: "consensus query outlier",
 }
 
 
@@ -55,10 +58,13 @@ class SegParams:
     def from_spc(cls, spc) -> "SegParams":
         """From a reference-style SigProcConfig (attribute access as in sig_proc.py:414-534)."""
         seg = spc.segmentation
-        if getattr(seg, "consensus_refinement", False):
-            raise NotImplementedError("consensus_refinement is not implemented by the HIP engine")
         k = seg.barcode_num_events
-        if not isinstance(k, (int, np.integer)):
+        if getattr(seg, "consensus_refinement", False):
+            if isinstance(k, (int, np.integer)):
+                # sig_proc.py:455-459
+                raise ValueError("barcode_num_events is an integer in consensus refinement mode, use a tuple instead")
+            k = int(k[1])
+        elif not isinstance(k, (int, np.integer)):
             raise ValueError("barcode_num_events must be an int outside consensus refinement mode")
         return cls(
             padding=int(spc.sig_extract.padding),
@@ -88,6 +94,51 @@ class SegParams:
             self.running_stat_width, self.num_events, int(self.accept_less_cpts),
             _lib.NORM_CODES[self.seg_norm], self.barcode_num_events, int(f64), float(self.outlier_thresh),
         )
+
+
+@dataclass
+class RefineParams:
+    """segmentation.consensus_* knobs of the refinement branch (config/sig_proc.py:57-66) + the consensus query
+    (``warpdemux._consensus.ALL[segmentation.consensus_model]``, passed in by the caller like the reference's
+    ``detect_results_to_fpt(..., consensus_query)``)."""
+
+    query: np.ndarray = None
+    subseq_norm: str = "mean"
+    penalty: float = 1.5
+    psi: tuple = (5, 0, 40, 0)
+    ub_start: int = 18
+    lb_end: int = 69
+    ub_end: int = 97
+    barcode_segm_events: int = 25
+    barcode_keep_events: int = 25
+
+    @classmethod
+    def from_spc(cls, spc, consensus_query) -> "RefineParams":
+        seg = spc.segmentation
+        if getattr(seg, "refinement_optimal_cpts", False):
+            raise NotImplementedError("refinement_optimal_cpts (ruptures KernelCPD) is not offered by the HIP engine")
+        k = seg.barcode_num_events
+        if isinstance(k, (int, np.integer)):
+            raise ValueError("barcode_num_events is an integer in consensus refinement mode, use a tuple instead")
+        if not isinstance(k, (tuple, list, np.ndarray)):
+            raise TypeError("barcode_num_events must be a tuple, list or numpy array when using multiple values")
+        q = np.ascontiguousarray(consensus_query, dtype=np.float64)
+        if q.ndim != 1 or q.size == 0:
+            raise ValueError("consensus refinement needs a 1-D consensus query")
+        return cls(query=q, subseq_norm=str(seg.consensus_subseq_match_normalization),
+                   penalty=float(seg.consensus_subseq_match_penalty),
+                   psi=tuple(int(v) for v in seg.consensus_subseq_match_psi),
+                   ub_start=int(seg.consensus_subseq_match_ub_start), lb_end=int(seg.consensus_subseq_match_lb_end),
+                   ub_end=int(seg.consensus_subseq_match_ub_end), barcode_segm_events=int(k[0]),
+                   barcode_keep_events=int(k[1]))
+
+    def to_c(self) -> "_lib.RefineParamsC":
+        if self.subseq_norm not in _lib.NORM_CODES:
+            raise ValueError(f"Normalization method {self.subseq_norm} not recognized.")
+        self._q = np.ascontiguousarray(self.query, dtype=np.float64)   # kept alive with the object
+        return _lib.RefineParamsC(self._q.ctypes.data, int(self._q.size), _lib.NORM_CODES[self.subseq_norm],
+                                  float(self.penalty), (C.c_int32 * 4)(*[int(v) for v in self.psi]), self.ub_start,
+                                  self.lb_end, self.ub_end, self.barcode_segm_events, self.barcode_keep_events)
 
 
 @dataclass
@@ -148,6 +199,7 @@ class FingerprintBatch:
     dwell: np.ndarray    # (n, K) int64
     stats: np.ndarray    # (n, 6) float64: dt_med, dt_mad, event_mean, event_std, event_med, event_mad
     status: np.ndarray   # (n,) int32, WDX_READ_*
+    refine_idx: Optional[np.ndarray] = None   # (n, 3) int32 seg_cons_query_start / _end, sig_barcode_start (refinement)
 
     @property
     def success(self) -> np.ndarray:
@@ -181,6 +233,33 @@ def fingerprint_batch(signals, adapter_start, adapter_end, params: SegParams, su
         )
     )
     return FingerprintBatch(fpt, dwell, stats, status)
+
+
+def fingerprint_refine_batch(signals, adapter_start, adapter_end, params: SegParams, refine: RefineParams, success=None,
+                             device=None) -> FingerprintBatch:
+    """Consensus-refinement branch on a (n_reads, stride) float32 minibatch; K = refine.barcode_keep_events."""
+    sig = np.asarray(signals)
+    if sig.ndim != 2:
+        raise ValueError("signals must be a 2-D (n_reads, stride) array")
+    sig = np.ascontiguousarray(sig, dtype=np.float32)
+    n, stride = sig.shape
+    a_s = np.ascontiguousarray(adapter_start, dtype=np.int32)
+    a_e = np.ascontiguousarray(adapter_end, dtype=np.int32)
+    if a_s.shape != (n,) or a_e.shape != (n,):
+        raise ValueError("adapter_start/adapter_end must have one entry per read")
+    ok = None if success is None else np.ascontiguousarray(success, dtype=np.uint8)
+    pc, rc = params.to_c(), refine.to_c()
+    K = refine.barcode_keep_events
+    fpt = np.empty((n, K), dtype=np.float64)
+    dwell = np.empty((n, K), dtype=np.int64)
+    stats = np.empty((n, 6), dtype=np.float64)
+    idx = np.empty((n, 3), dtype=np.int32)
+    status = np.empty(n, dtype=np.int32)
+    ctx = _lib.default_context(device)
+    _lib.check(_lib.load().wdx_fingerprint_refine_batch(
+        ctx.handle, _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e), _lib.ptr(ok), C.byref(pc), C.byref(rc),
+        _lib.ptr(fpt), _lib.ptr(dwell), _lib.ptr(stats), _lib.ptr(idx), _lib.ptr(status)))
+    return FingerprintBatch(fpt, dwell, stats, status, idx)
 
 
 @dataclass
@@ -265,26 +344,41 @@ def demux_batch(signals, adapter_start, adapter_end, params: SegParams, success=
     return DemuxBatch(status, call, dist, fpt)
 
 
-def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequence, read_ids: Optional[Sequence[str]] = None, device=None) -> List[ReadResult]:
+def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequence, read_ids: Optional[Sequence[str]] = None,
+                                device=None, consensus_query=None) -> List[ReadResult]:
     """Batched `detect_results_to_fpt`: one ReadResult per row, identical fields to the reference's
-    per-read call (sig_proc.py:590-605) plus the `barcode_fpt_wrapper` read-id (file_proc.py:216)."""
+    per-read call (sig_proc.py:590-605) plus the `barcode_fpt_wrapper` read-id (file_proc.py:216).  With
+    ``spc.segmentation.consensus_refinement`` the caller passes the consensus signal like the reference does."""
     params = SegParams.from_spc(spc)
+    refine = None
+    if getattr(spc.segmentation, "consensus_refinement", False):
+        if consensus_query is None or np.asarray(consensus_query).size == 0:
+            raise ValueError("consensus_model must be specified when consensus_refinement is True")
+        refine = RefineParams.from_spc(spc, consensus_query)
     n = len(detect_results)
     ok = np.array([bool(d.success) for d in detect_results], dtype=np.uint8)
     a_s = np.array([d.adapter_start if (d.success and d.adapter_start is not None) else 0 for d in detect_results], dtype=np.int32)
     a_e = np.array([d.adapter_end if (d.success and d.adapter_end is not None) else 0 for d in detect_results], dtype=np.int32)
-    fb = fingerprint_batch(calibrated_signals, a_s, a_e, params, success=ok, device=device)
+    if refine is None:
+        fb = fingerprint_batch(calibrated_signals, a_s, a_e, params, success=ok, device=device)
+    else:
+        fb = fingerprint_refine_batch(calibrated_signals, a_s, a_e, params, refine, success=ok, device=device)
     out = []
     for i in range(n):
         st = int(fb.status[i])
         rid = None if read_ids is None else read_ids[i]
-        if st == 0:
+        extra = {}
+        if refine is not None and st in (0, 6):
+            q = fb.refine_idx[i]
+            extra = dict(seg_cons_query_start=int(q[0]), seg_cons_query_end=int(q[1]), sig_barcode_start=int(q[2]))
+        if st == 0 or st == 6:
             s = fb.stats[i]
             out.append(ReadResult(
-                read_id=rid, success=True, fail_reason="", detect_results=detect_results[i],
-                barcode_fpt=fb.fpt[i].copy(), dwell_times=fb.dwell[i].copy(),
+                read_id=rid, success=st == 0, fail_reason=FAIL_REASONS[st], detect_results=detect_results[i],
+                barcode_fpt=fb.fpt[i].copy() if st == 0 else np.array([]),
+                dwell_times=fb.dwell[i].copy() if st == 0 else np.array([]),
                 adapter_dt_med=float(s[0]), adapter_dt_mad=float(s[1]), adapter_event_mean=float(s[2]),
-                adapter_event_std=float(s[3]), adapter_event_med=float(s[4]), adapter_event_mad=float(s[5]),
+                adapter_event_std=float(s[3]), adapter_event_med=float(s[4]), adapter_event_mad=float(s[5]), **extra,
             ))
         elif st == 5:
             # barcode_fpt_wrapper's except-branch builds a bare record (file_proc.py:220-224)
@@ -300,7 +394,5 @@ def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequenc
 
 def detect_results_to_fpt(calibrated_signal, spc, detect_results, consensus_query=np.array([])) -> ReadResult:
     """Per-read signature of the reference (sig_proc.py:394-399); a batch of one."""
-    if np.asarray(consensus_query).size:
-        raise NotImplementedError("consensus refinement is not implemented by the HIP engine")
     sig = np.asarray(calibrated_signal, dtype=np.float32).reshape(1, -1)
-    return detect_results_to_fpt_batch(sig, spc, [detect_results])[0]
+    return detect_results_to_fpt_batch(sig, spc, [detect_results], consensus_query=consensus_query)[0]
