@@ -306,6 +306,12 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
                                 const wdx_seg_params *p, int32_t *d_status, long long *d_prof,
                                 int64_t prof_reads, int32_t fast_path, int32_t stop_phase, void *stream);
 
+/* Self-test: d_fast[i] = the fast fingerprint kernel's unscaled quotient/sqrt sequence for dm[i] / sqrt(vs[i]),
+ * d_ref[i] = the compiler's general float64 expansions of the same expression.  The two must agree bit for bit
+ * on the kernel's value range (variance sums in [2^-402, 2^261], mean differences in {0} U [2^-201, 2^129]). */
+int wdx_selftest_score_dev(wdx_ctx *ctx, const double *d_dm, const double *d_vs, int64_t n, double *d_fast,
+                           double *d_ref, void *stream);
+
 /* Diagnostic: stream n floats with coalesced dword loads (known byte count) to calibrate the
  * FETCH_SIZE PMC counter for the fingerprint kernel's access pattern. */
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream);

@@ -432,6 +432,37 @@ def test_clip_bound_rules_float32_and_float64():
     assert sig_proc.SegParams(outlier_thresh=np.float64(2.7)).to_c().clip_bounds_f64 == 1
 
 
+def test_fast_score_sequences_match_the_compilers_sqrt_and_division():
+    """The fast kernel's t-score uses the sqrt / quotient iterations without their range scaling
+    (wdx_fingerprint_fast.inc: fast_sqrt_mid, fast_div_mid).  Bit-identity with the general float64 sqrt() and '/'
+    over the documented value range is asserted here, so a toolchain that changes its expansions fails loudly."""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(99)
+    n = 1 << 20
+    # variance sums: squares of float64 differences of float32 values -> [2^-402, 2^261]; mean differences
+    # {0} U [2^-201, 2^129]; plus realistic pA-scale values and exact powers of two / neighbours of them
+    vs = np.concatenate([
+        2.0 ** rng.uniform(-402, 261, n // 2), rng.uniform(1e-3, 1e5, n // 4), 2.0 ** rng.integers(-402, 262, n // 8).astype(np.float64),
+        np.nextafter(2.0 ** rng.integers(-400, 260, n // 8).astype(np.float64), np.inf)])
+    dm = np.concatenate([
+        2.0 ** rng.uniform(-201, 129, n // 2), rng.uniform(0, 200, n // 4), np.zeros(n // 8),
+        2.0 ** rng.integers(-201, 130, n // 8).astype(np.float64)])
+    rng.shuffle(dm)
+    t_dm, t_vs = torch.from_numpy(dm).cuda(), torch.from_numpy(vs).cuda()
+    fast, ref = torch.empty_like(t_dm), torch.empty_like(t_dm)
+    ctx = _lib.default_context()
+    _lib.check(_lib.load().wdx_selftest_score_dev(ctx.handle, C.c_void_p(t_dm.data_ptr()), C.c_void_p(t_vs.data_ptr()), dm.size,
+                                                  C.c_void_p(fast.data_ptr()), C.c_void_p(ref.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    f, r = fast.cpu().numpy(), ref.cpu().numpy()
+    assert np.array_equal(f.view(np.uint64), r.view(np.uint64)), int((f.view(np.uint64) != r.view(np.uint64)).sum())
+    assert np.array_equal(r, dm / np.sqrt(vs))   # and the device's general expansions are the correctly rounded ones
+
+
 # ------------------------------------------------------------------------ fused device pipeline ----
 
 def test_device_synth_matches_numpy_and_fused_pipeline():

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the per-round measurement set on the GPU box (run through gpurun from the repo root):
+#   tools/collect_round_profiles.sh r02a
+# -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
+#    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
+#    fast fingerprint kernel.  Copy what should be judged into profiles/.
+TAG=${1:-r02}
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 bench.py > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err
+D=gpurun_out/${TAG}_stats; rm -rf $D
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$D -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-secondary) > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
+cp $(find $D -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
+python3 tools/collect_traffic.py --out gpurun_out/${TAG}_traffic > gpurun_out/${TAG}_traffic.log 2>&1
+cp profiles/traffic.json gpurun_out/${TAG}_traffic.json 2>/dev/null
+python3 tools/collect_sq.py --tag ${TAG} --out gpurun_out/${TAG}_sq > gpurun_out/${TAG}_sq.log 2>&1
+python3 tools/phase_counters.py 262144 > gpurun_out/${TAG}_phase_counters.txt 2> gpurun_out/${TAG}_phase_counters.err
+python3 tools/profile_fingerprint.py 16384 1 1000000 > gpurun_out/${TAG}_fast_kernel_phase_shares.txt 2>&1
+rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_traffic gpurun_out/${TAG}_sq gpurun_out/phase_pmc
+ls -la gpurun_out | grep ${TAG}

@@ -31,7 +31,7 @@ def run_pass(i, counters, outdir, reads):
     os.makedirs(d, exist_ok=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--reads", str(reads), "--steps", "1", "--warmup", "0",
-           "--no-cpu"]
+           "--no-cpu", "--no-secondary"]
     with open(os.path.join(d, "bench.log"), "w") as fh:
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=fh, stderr=subprocess.STDOUT,
                        check=True)
@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sq"))
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)
     res = {}
     for i, counters in enumerate(PASSES):
         for r in run_pass(i, counters, args.out, args.reads):
@@ -76,9 +77,10 @@ def main():
         if avg.get("SQ_BUSY_CYCLES") and avg.get("SQ_ACTIVE_INST_VALU"):
             pass
         out["kernels"][k] = e
-    p = os.path.join(ROOT, "gpurun_out", f"{args.tag}_sq_counters.json")
-    with open(p, "w") as fh:
-        json.dump(out, fh, indent=1)
+    for p in (os.path.join(ROOT, "gpurun_out", f"{args.tag}_sq_counters.json"),
+              os.path.join(ROOT, "gpurun_out", "sq_counters_latest.json")):   # copy both under profiles/ afterwards
+        with open(p, "w") as fh:
+            json.dump(out, fh, indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in out["kernels"].items()},
                      indent=1))
 

@@ -26,7 +26,7 @@ def run_pass(counter, outdir, reads, parse_only=False):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--reads", str(reads), "--steps", "1", "--warmup", "0",
-           "--no-cpu", "--calib"]
+           "--no-cpu", "--no-secondary", "--calib"]
     if not parse_only:
         with open(os.path.join(d, "bench.log"), "w") as fh:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=fh, stderr=subprocess.STDOUT, check=True)
@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     ap.add_argument("--parse-only", action="store_true", help="re-read existing CSVs under --out")
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)
     fr, bj = run_pass("FETCH_SIZE", args.out, args.reads, args.parse_only)
     wr, _ = run_pass("WRITE_SIZE", args.out, args.reads, args.parse_only)
     fetch, write = per_kernel(fr, "FETCH_SIZE"), per_kernel(wr, "WRITE_SIZE")
@@ -75,6 +76,9 @@ def main():
     res = {
         "kernel": "fingerprint_fast_kernel",
         "reads_per_launch": n_reads // max(fn // 2, 1),
+        # what bench.py looks up: the whole step (all launch slices of one pass over the batch)
+        "reads_per_step": n_reads,
+        "hbm_bytes_per_step": (fetch_b + write_b) * max(fn // 2, 1),
         "algorithmic_bytes_per_launch": bj["roofline"]["algorithmic_bytes_per_launch"],
         "hbm_bytes_per_launch": fetch_b + write_b,
         "fetch_bytes_per_launch_corrected": fetch_b,

@@ -39,7 +39,7 @@ EXPORTS = [
     "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
-    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev",
+    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev",
 ]
 
 
@@ -208,6 +208,8 @@ def load():
         L.wdx_kernel_time_reset.argtypes = [vp]
         L.wdx_fingerprint_profile_dev.restype = C.c_int
         L.wdx_fingerprint_profile_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, P(SegParamsC), vp, vp, i64, i32, i32, vp]
+        L.wdx_selftest_score_dev.restype = C.c_int
+        L.wdx_selftest_score_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
         L.wdx_calib_read_dev.restype = C.c_int
         L.wdx_calib_read_dev.argtypes = [vp, vp, i64, vp, vp]
         L.wdx_synth_lengths_dev.restype = C.c_int

@@ -972,6 +972,16 @@ int wdx_kernel_time_reset(wdx_ctx *ctx) {
     return WDX_SUCCESS;
 }
 
+int wdx_selftest_score_dev(wdx_ctx *ctx, const double *d_dm, const double *d_vs, int64_t n, double *d_fast,
+                           double *d_ref, void *stream) {
+    WDX_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!d_dm || !d_vs || !d_fast || !d_ref))) {
+        set_error("selftest_score_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    return launch_score_selftest(d_dm, d_vs, n, d_fast, d_ref, (hipStream_t)stream);
+}
+
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream) {
     WDX_ENTER(ctx);
     return launch_calib_read(d_p, n, d_out, (hipStream_t)stream);

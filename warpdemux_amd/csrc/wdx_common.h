@@ -106,6 +106,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        const Knobs &knobs, int64_t *n_launches = nullptr, long long *d_prof = nullptr,
                        int64_t prof_reads = 0, int stop_phase = 0, const struct RefineDev *rf = nullptr);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
+int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------
 int launch_synth_lengths(uint64_t seed, int64_t first_read, int64_t n, int32_t n_barcodes,

@@ -1192,6 +1192,23 @@ int fill_refine_dev(const wdx_refine_params &rp, const double *d_query, int32_t 
 }
 void free_refine_dev(RefineDev *rf) { delete rf; }
 
+// Self-test of the t-score's unscaled sqrt / quotient sequences (fast_sqrt_mid, fast_div_mid) against the
+// compiler's general float64 sqrt() and '/': same bits on the documented value range is what the fast path's
+// bit-identity rests on; a toolchain whose expansions change shows up here (tests/test_gpu_parity.py).
+__global__ void score_selftest_kernel(const double *__restrict__ dm, const double *__restrict__ vs, int64_t n,
+                                      double *__restrict__ fast, double *__restrict__ ref) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = fast_div_mid(dm[i], fast_sqrt_mid(vs[i]));
+    ref[i] = dm[i] / sqrt(vs[i]);
+}
+int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream) {
+    if (n <= 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(score_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dm, vs, n, fast, ref);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 8 * (n_reads > 0 ? n_reads : 0); }
 
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
@@ -1286,7 +1303,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
             fprintf(stderr, "[wdx] fast kernel capF=%d capP=%d lds=%zu B -> %d workgroups/CU\n", capF, capP, flds, nb);
         }
-        const int64_t slice = (1ll << 31) / FB;  // grid.x * block.x must stay below 2^32
+        // grid.x * block.x must stay below 2^32: equal launch slices of at most 2^31 / FB reads
+        const int64_t max_slice = (1ll << 31) / FB, n_slices = (n_reads + max_slice - 1) / max_slice;
+        const int64_t slice = (n_reads + n_slices - 1) / n_slices;
         for (int64_t base = 0; base < n_reads; base += slice) {
             const int64_t n = n_reads - base < slice ? n_reads - base : slice;
             F.a.block_base = base;
