@@ -463,6 +463,25 @@ def test_fast_score_sequences_match_the_compilers_sqrt_and_division():
     assert np.array_equal(r, dm / np.sqrt(vs))   # and the device's general expansions are the correctly rounded ones
 
 
+def test_dtaidistance_cross_check_if_available():
+    """the DTW seam is parity-unpinned because dtaidistance is not in the reference tree.  If the
+    box this runs on happens to have the library, compare the genuine call of parallel_distances.py:59-67 with the
+    engine on >= 1e4 pairs of both shapes; otherwise skip (never fail for its absence)."""
+    dtai = pytest.importorskip("dtaidistance")
+    from dtaidistance import dtw
+
+    rng = np.random.default_rng(21)
+    for nX, nY, L in ((1200, 10, 110), (16, 851, 25)):
+        X, Y = rng.normal(size=(nX, L)), rng.normal(size=(nY, L))
+        stack = np.vstack([X, Y])
+        ref = dtw.distance_matrix(stack, block=((0, nX), (nX, nX + nY)), parallel=False, use_c=True, only_triu=True,
+                                  window=15, penalty=0.1)[:nX, nX:].astype(np.float32)
+        mine = pdist.distance_matrix_to(X, Y, window=15, penalty=0.1, n_jobs=1)
+        assert mine.size >= 10_000
+        assert np.array_equal(mine.argmin(1), ref.argmin(1)), dtai.__version__
+        np.testing.assert_allclose(mine, ref, rtol=RTOL, atol=0)
+
+
 # ------------------------------------------------------------------------ fused device pipeline ----
 
 def test_device_synth_matches_numpy_and_fused_pipeline():
