@@ -13,7 +13,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwdx_hip.so")
+# $WDX_LIB_PATH: development only (tools/ab.sh benches two builds of the library in one GPU session)
+LIB_PATH = os.environ.get("WDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libwdx_hip.so")
 
 WDX_SUCCESS = 0
 WDX_ERR_INVALID = -1
