@@ -48,3 +48,7 @@ def test_predictions_csv_matches_reference_writer(tmp_path):
     p = str(tmp_path / "predictions.csv.gz")
     ff.save_predictions(df, p)
     assert gzip.open(p, "rb").read() == g["csv_text"].tobytes()
+    # the same table straight from the arrays (no intermediate frame, no per-read objects)
+    p2 = str(tmp_path / "predictions2.csv.gz")
+    ff.save_predictions(ff.predictions_frame(g["read_ids"], g["y_pred"], g["prob"], g["conf"], label_mapper), p2)
+    assert gzip.open(p2, "rb").read() == g["csv_text"].tobytes()
