@@ -140,3 +140,33 @@ def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_refinement_parameters_validate_like_the_reference():
+    from types import SimpleNamespace as NS
+
+    seg = NS(min_obs_per_base=9, running_stat_width=18, num_events=120, accept_less_cpts=False, normalization="mean",
+             barcode_num_events=[25, 20], consensus_refinement=True, consensus_subseq_match_normalization="mean",
+             consensus_subseq_match_penalty=1.5, consensus_subseq_match_psi=[5, 0, 40, 0],
+             consensus_subseq_match_ub_start=18, consensus_subseq_match_lb_end=69, consensus_subseq_match_ub_end=97,
+             refinement_optimal_cpts=False)
+    spc = NS(sig_extract=NS(padding=100, normalization="none"), core=NS(sig_norm_outlier_thresh=5.0), segmentation=seg)
+    q = np.linspace(-1, 1, 84)
+    rp = sig_proc.RefineParams.from_spc(spc, q)
+    assert (rp.barcode_segm_events, rp.barcode_keep_events, rp.psi, rp.penalty) == (25, 20, (5, 0, 40, 0), 1.5)
+    assert sig_proc.SegParams.from_spc(spc).barcode_num_events == 20       # K of the outputs = barcode_num_events[1]
+    c = rp.to_c()
+    assert c.n_query == 84 and list(c.psi) == [5, 0, 40, 0] and c.barcode_keep_events == 20
+    seg.barcode_num_events = 25          # sig_proc.py:455-459
+    with pytest.raises(ValueError, match="use a tuple instead"):
+        sig_proc.RefineParams.from_spc(spc, q)
+    seg.barcode_num_events = [25, 25]
+    seg.refinement_optimal_cpts = True   # ruptures KernelCPD: not offered
+    with pytest.raises(NotImplementedError):
+        sig_proc.RefineParams.from_spc(spc, q)
+    seg.refinement_optimal_cpts = False
+    with pytest.raises(ValueError):
+        sig_proc.RefineParams.from_spc(spc, np.zeros((2, 2)))
+    seg.consensus_subseq_match_normalization = "zscore"
+    with pytest.raises(ValueError, match="not recognized"):
+        sig_proc.RefineParams.from_spc(spc, q).to_c()

@@ -268,3 +268,43 @@ def test_bench_starts_its_own_ranks():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["reads_total"] == 300000 and rec["config"]["workload"].startswith("C4")
     assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_live_tick_edge_cases():
+    refs = np.random.default_rng(1).normal(size=(6, 110))
+    ld = LiveDemux(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=110), max_reads=4, max_samples=2000)
+    try:
+        # an empty tick
+        r = ld.tick([], np.zeros(0, np.int32), np.zeros(0, np.int32))
+        assert r.status.size == 0 and r.call.size == 0 and r.dist.shape == (0, 6)
+        # empty rows, inverted windows, windows entirely outside the row: all soft failures, nothing raised
+        rows = [np.zeros(0, np.float32), np.full(3000, 80, np.float32), np.full(500, 80, np.float32)]
+        r = ld.tick(rows, np.array([0, 2000, 900], np.int32), np.array([0, 100, 1200], np.int32))
+        fpt, status, D, call = _oracle_tick(rows, [0, 2000, 900], [0, 100, 1200], 110, refs)
+        assert np.array_equal(r.status, status) and (r.status != 0).all() and (r.call == -1).all()
+        assert np.isnan(r.dist).all()
+        # float64 / non-contiguous rows are converted, not reinterpreted
+        spec = synth.SynthSpec(n_barcodes=6)
+        x = _ragged_rows(spec, 4242, 1)[0]
+        a = ld.tick([x], [0], [x.size - 100], want_fpt=True)
+        b = ld.tick([x.astype(np.float64)], [0], [x.size - 100], want_fpt=True)
+        c = ld.tick([np.repeat(x, 2)[::2]], [0], [x.size - 100], want_fpt=True)
+        assert a.status[0] == 0 and _same(a.fpt, b.fpt) and _same(a.fpt, c.fpt)
+        with pytest.raises(ValueError):
+            ld.tick([x], [0, 1], [5])
+        # the C ABI refuses a dist buffer sized for another reference count, and the SVM tail without a model
+        import ctypes as C
+        L = _lib.load()
+        ptrs = (C.c_void_p * 1)(x.ctypes.data)
+        ln = np.array([x.size], np.int32)
+        z = np.zeros(1, np.int32)
+        pc = ld.params.to_c()
+        st = np.zeros(1, np.int32)
+        with pytest.raises(ValueError, match="references"):
+            _lib.check(L.wdx_live_tick(ld.ctx.handle, ptrs, _lib.ptr(ln), 1, _lib.ptr(z), _lib.ptr(ln), None, C.byref(pc), 7,
+                                       0, None, None, None, _lib.ptr(st), None, None, None))
+        with pytest.raises(_lib.WdxError, match="svm"):
+            _lib.check(L.wdx_live_tick(ld.ctx.handle, ptrs, _lib.ptr(ln), 1, _lib.ptr(z), _lib.ptr(ln), None, C.byref(pc), 6,
+                                       1, None, None, None, _lib.ptr(st), None, None, None))
+    finally:
+        ld.close()
