@@ -395,7 +395,8 @@ static int64_t wdx_oracle_scores_to_cpts_impl(const double *scores, int64_t n_sc
         stable_argsort(h, np_, order, tmp);
         int64_t take = np_ < num_events ? np_ : num_events;
         /* mark the `take` highest, then emit ascending by position (== valid_cpts.sort()) */
-        unsigned char *sel = (unsigned char *)calloc((size_t)np_, 1);
+        unsigned char *sel = (unsigned char *)a_alloc((size_t)(np_ > 0 ? np_ : 1));
+        memset(sel, 0, (size_t)(np_ > 0 ? np_ : 1));
         for (int64_t i = np_ - take; i < np_; i++) sel[order[i]] = 1;
         int64_t m = 0;
         cpts[m++] = 0; /* peaks >= 1 so valid_cpts[0] = peak + W != 0 always */
