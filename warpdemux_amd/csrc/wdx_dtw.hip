@@ -242,8 +242,10 @@ __device__ __forceinline__ void dtw_short_row(double (&D)[L], const double xi, c
         const double up = D[j];
         double d = xi - y[j];
         d = d * d;
-        double t = (j == jlo ? up : min_f64(up, left)) + p2;
-        t = min_f64(t, diag);
+        // min(min(up, left) + p2, diag) == min(min(up + p2, diag), left + p2) (rounding is monotone): the part that
+        // does not depend on the cell to the left is off the row's dependency chain (3 dependent ops per cell, not 4)
+        double t = __builtin_fmin(up + p2, diag);
+        if (j != jlo) t = __builtin_fmin(t, left + p2);
         const double v = d + t;
         diag = up;
         D[j] = v;
@@ -493,11 +495,21 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
     // and the argmin is a second, tiny kernel.
     int32_t *fused_argmin = nullptr;
     int rpb = (int)nB;
-    if (gx >= 2048 || nB == 1) {
+    if (gx >= 8 * 3072 || nB == 1 || (gx >= 2048 && nB < 32)) {
         fused_argmin = d_argmin;
     } else {
-        int64_t want_y = (2048 + gx - 1) / gx;
-        if (want_y > nB) want_y = nB;
+        // A wave lives for the whole launch (one block = one wave walking its refs): with about as many waves as
+        // the chip has slots (256 CUs x 4 SIMDs x 3 waves of this kernel = 3072) a few stragglers double the
+        // launch time -- 1563 x 2 blocks ran at 67 % of the rate of the same kernel on a long grid.  Aim for
+        // >= 8 waves per slot (dynamic balancing by the dispatcher), at least 16 refs per block.
+        int64_t max_y = (nB + 15) / 16;
+        int64_t want_y = (8 * 3072 + gx - 1) / gx;
+        if (gx * max_y <= 3072) {  // fits the chip at once anyway: latency-bound -- as many short blocks as it takes
+            want_y = (2048 + gx - 1) / gx;
+            max_y = nB;
+        }
+        if (want_y > max_y) want_y = max_y;
+        if (want_y < 1) want_y = 1;
         rpb = (int)((nB + want_y - 1) / want_y);
     }
     if (d_argmin && (sA != nB || sB != 1)) {
