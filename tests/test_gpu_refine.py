@@ -119,3 +119,47 @@ def test_refinement_through_the_reference_shaped_api(golden_dir):
     spc.segmentation.barcode_num_events = 25
     with pytest.raises(ValueError, match="use a tuple instead"):
         sig_proc.detect_results_to_fpt_batch(mb, spc, drs, consensus_query=consensus)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("WDX_SOAK_SEEDS", "12"))))   # soak: WDX_SOAK_SEEDS=200
+def test_refinement_randomised_parameters_vs_oracle(seed):
+    """Random queries, event counts, window widths, penalties, relaxations and normalisations: engine == oracle on
+    every output of the refinement branch, whatever the status."""
+    rng = np.random.default_rng(1000 + seed)
+    nq = int(rng.integers(8, 97))
+    query = rng.normal(0, 1, nq)
+    E = int(rng.integers(max(nq + 10, 40), 128))
+    E2 = int(rng.integers(5, 40))
+    keep = int(rng.integers(1, E2 + 2))
+    w = int(rng.choice([6, 12, 18, 24]))
+    d = int(rng.integers(2, w // 2 + 2))
+    n = 40
+    rows = []
+    for i in range(n):
+        n_lead = int(rng.integers(0, 30))
+        lv = list(rng.normal(0, 1, n_lead)) + list(query + rng.normal(0, 0.05, nq)) + list(rng.normal(0, 1, E2 + 12))
+        lv = np.array(lv) * 12.0 + 85.0
+        dw = rng.integers(2 * d + 1, 5 * d + 12, lv.size)
+        x = np.repeat(lv, dw) + rng.normal(0, rng.uniform(0.5, 2.5), int(dw.sum()))
+        rows.append(x.astype(np.float32)[:11000])
+    stride = max(r.size for r in rows)
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, : r.size] = r
+    pad = int(rng.choice([0, 20, 100]))
+    a_s = np.full(n, pad, dtype=np.int32)
+    a_e = np.array([r.size - pad for r in rows], dtype=np.int32)
+    seg = dict(padding=pad, min_obs_per_base=d, running_stat_width=w, num_events=E,
+               seg_norm=str(rng.choice(["mean", "median"])), outlier_thresh=float(rng.choice([3.0, 5.0])))
+    ref = dict(subseq_norm=str(rng.choice(["mean", "median", "none"])), penalty=float(rng.choice([0.0, 0.5, 1.5, 3.0])),
+               psi=(int(rng.integers(0, 8)), 0, int(rng.integers(0, 60)), 0), ub_start=int(rng.integers(5, 60)),
+               lb_end=int(rng.integers(0, nq)), ub_end=int(rng.integers(nq, 160)), barcode_segm_events=E2,
+               barcode_keep_events=keep)
+    fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=keep, **seg),
+                                           sig_proc.RefineParams(query=query, **ref))
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=keep, **seg),
+                                                                  orc.RefineParams(query=query, **ref))
+    assert np.array_equal(fb.status, status), (seed, fb.status.tolist(), status.tolist())
+    good, rep = status == 0, (status == 0) | (status == 6)
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]), seed
+    assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep]), seed
