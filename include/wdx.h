@@ -106,6 +106,7 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_SVM_SCALAR 4        /* scalar SVM tail kernel instead of the matrix-core one             */
 #define WDX_OPT_DEBUG_OCCUPANCY 5   /* print the fast fingerprint kernel's workgroups per CU to stderr   */
 #define WDX_OPT_FAST_PEAK_CAP 6     /* peak-list capacity of the fast fingerprint kernel (0 = built-in)  */
+#define WDX_OPT_FAST_EXACT_SCORES 7 /* fast fingerprint kernel: exact t-scores from the first attempt     */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

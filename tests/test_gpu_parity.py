@@ -257,6 +257,55 @@ def test_fast_and_slow_paths_agree(monkeypatch):
             assert _same(fast.stats[good], stats[good])
 
 
+@contextlib.contextmanager
+def _option(opt, value, device=None):
+    ctx = _lib.default_context(device)
+    ctx.set_option(opt, value)
+    try:
+        yield
+    finally:
+        ctx.set_option(opt, 0)
+
+
+def test_banded_score_keys_match_exact_scores_and_oracle():
+    """The fast kernel takes its order decisions (local maxima, suppression, top-E cut) on approximate score keys and
+    only outside an error band; anything inside the band is redone from the reference's exact scores.  The result
+    must be the bits of the exact-scores kernel (WDX_OPT_FAST_EXACT_SCORES) and of the oracle on data that stresses
+    the band: a large offset with little noise (cancellation in S2 - S1^2/12 -> variance floor), flat clipped
+    stretches and near-constant windows (ties, plateaus), tiny and huge scales."""
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 123_000, 500, 9000)
+    rng = np.random.default_rng(5)
+    cases = {"plain": mb.copy()}
+    off = mb.copy()
+    off[:, :] = (mb - np.float32(80.0)) * np.float32(0.002) + np.float32(900.0)  # sigma ~ 0.004 on a level of 900
+    cases["offset"] = off
+    cases["tiny"] = mb * np.float32(1e-12)
+    cases["huge"] = mb * np.float32(3e9)
+    flat = mb.copy()
+    for r in range(0, 500, 3):  # stretches of equal samples inside the window: zero-variance windows, ties
+        p0 = int(rng.integers(300, 3000))
+        flat[r, p0:p0 + int(rng.integers(10, 90))] = flat[r, p0]
+    cases["flat"] = flat
+    rep = mb.copy()
+    rep[:, 1000:1600] = rep[:, 400:1000]  # repeated stretch: equal scores 600 positions apart (top-E ties)
+    cases["repeat"] = rep
+    for name, data in cases.items():
+        for K in (25, 110):
+            ph = sig_proc.SegParams(barcode_num_events=K)
+            a = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
+            with _option(_lib.OPT_FAST_EXACT_SCORES, 1):
+                b = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
+            assert np.array_equal(a.status, b.status), name
+            assert _same(a.fpt, b.fpt) and _same(a.dwell, b.dwell) and _same(a.stats, b.stats), name
+            fpt, dwell, stats, status = orc.fingerprint_batch(data, a_s, a_e, orc.SegParams(barcode_num_events=K))
+            assert np.array_equal(a.status, status), name
+            good = status == 0
+            assert good.sum() > 400, name
+            assert _same(a.fpt[good], fpt[good]) and _same(a.dwell[good], dwell[good]), name
+            assert _same(a.stats[good], stats[good]), name
+
+
 def test_adc_quantised_signals_match_oracle():
     """Real pA signals are (int16 + offset) * scale: a few hundred distinct values, hence many exact
     duplicates (radix bins that never shrink), equal scores, plateaus and ties at the top-E cut.  The

@@ -2,7 +2,7 @@
 """Opcode-class table of one loop of a kernel from hipcc's --save-temps ISA (where do the VALU
 instructions of the t-score tile go?).
 
-    python tools/isa_opclass.py <file.s> <kernel-symbol-substring> [marker-opcode]
+    python tools/isa_opclass.py <file.s> <kernel-symbol-substring> [marker-opcode [min-count]]
 
 Finds the innermost loop (label ... backward branch) of the kernel that contains `marker-opcode`
 (default v_rsq_f64 -- the t-score tile is the only loop with a float64 reciprocal square root) and prints the
@@ -50,8 +50,8 @@ def kernel_body(lines, sym):
     for i, ln in enumerate(lines):
         if start is None and re.match(r"^[_A-Za-z0-9.$]*%s[_A-Za-z0-9.$]*:" % re.escape(sym), ln):
             start = i
-        elif start is not None and ln.strip().startswith("s_endpgm"):
-            return lines[start:i + 1]
+        elif start is not None and ln.startswith(".Lfunc_end"):  # (early exits put s_endpgm in mid-body)
+            return lines[start:i]
     raise SystemExit("kernel not found")
 
 
@@ -77,7 +77,8 @@ def main():
         m = re.match(r"^s_c?branch\S*\s+(\.LBB\d+_\d+)", ins)
         if m and m.group(1) in label_at and label_at[m.group(1)] <= k:
             loops.append((label_at[m.group(1)], k))
-    cand = [(a, b) for a, b in loops if any(marker in instrs[j] for j in range(a, b + 1))]
+    need = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # occurrences of the marker the loop must hold
+    cand = [(a, b) for a, b in loops if sum(marker in instrs[j] for j in range(a, b + 1)) >= need]
     if not cand:
         raise SystemExit("no loop with marker " + marker)
     a, b = min(cand, key=lambda t: t[1] - t[0])

@@ -48,6 +48,8 @@ for i in range(9):
     print(f"  {names[i]:22s} median {np.median(d[:, i]):9.0f}  mean {d[:, i].mean():9.0f}  share {d[:, i].sum() / tot.sum() * 100:5.1f}%")
 print("  suppression iterations: median %d  p99 %d  max %d" % (np.median(p[:, 10]), np.percentile(p[:, 10], 99), p[:, 10].max()))
 print("  n samples median %d, score positions median %d" % (np.median(p[:, 11]), np.median(p[:, 12])))
+if fast:
+    print("  attempts of P2..P4 (1 = approximate keys sufficed):", np.bincount(p[:, 14].astype(int), minlength=3).tolist())
 
 if fast:
     q = p[:, 16:23]

@@ -66,6 +66,7 @@ struct FpArgs {
     long long *prof;     // diagnostic build only: 32 int64 per read (cycle stamps etc.)
     int64_t prof_reads;
     int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
+    int exact_scores;    // fast kernel: exact t-scores from the first attempt (WDX_OPT_FAST_EXACT_SCORES)
     RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
 };
 
@@ -1243,7 +1244,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, RefineDev{}};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, knobs.fast_exact_scores ? 1 : 0, RefineDev{}};
     if (rf) {
         if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
             set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,
