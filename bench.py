@@ -60,6 +60,9 @@ def parse_args(argv=None):
                          "--cpu-seconds 0 verifies exactly this many")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--ctx-opt", action="append", default=[], metavar="ID=VALUE",
+                    help="diagnostic: wdx_ctx_set_option(ID, VALUE) on the bench context (experiments only; the line "
+                         "records it under config.ctx_options)")
     ap.add_argument("--calib", action="store_true", help="also stream the signal buffer once with the calibration "
                     "kernel (known byte count for the FETCH_SIZE counter; tools/collect_traffic.py)")
     return ap.parse_args(argv)
@@ -453,6 +456,9 @@ def run_rank(args):
     refs = make_refs(clean, synth, sig_proc, local_rank)
     params = sig_proc.SegParams(barcode_num_events=K_FPT)
     eng = DemuxEngine(refs, WINDOW, PENALTY, params, device=local_rank)
+    for kv in args.ctx_opt:
+        k, v = kv.split("=")
+        eng.ctx.set_option(int(k), int(v))
     reducer = dist.CountReducer(eng.ctx, prefer="torch" if host_collectives else None)
 
     # ---- the global read range and this rank's contiguous shard of it ----------------------------
@@ -586,6 +592,7 @@ def run_rank(args):
                 "reads_per_gpu": per_gpu,
                 "reads_total": total,
                 "failed_reads": n_fail,
+                **({"ctx_options": list(args.ctx_opt)} if args.ctx_opt else {}),
                 "sharding": "contiguous shards of one global read range (dist.shard_range), one process per GPU, "
                             "one int64[11] count all-reduce per step",
                 "count_allreduce": {"single": "none (one process)", "rccl": "wdx_reduce_counts (C ABI, RCCL)",
