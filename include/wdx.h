@@ -106,7 +106,8 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_SVM_SCALAR 4        /* scalar SVM tail kernel instead of the matrix-core one             */
 #define WDX_OPT_DEBUG_OCCUPANCY 5   /* print the fast fingerprint kernel's workgroups per CU to stderr   */
 #define WDX_OPT_FAST_PEAK_CAP 6     /* peak-list capacity of the fast fingerprint kernel (0 = built-in)  */
-#define WDX_OPT_FAST_EXACT_SCORES 7 /* fast fingerprint kernel: exact t-scores from the first attempt     */
+#define WDX_OPT_FAST_EXACT_SCORES 7 /* fast fingerprint kernel: exact t-scores, no approximate keys       */
+#define WDX_OPT_FAST_MAIN_CAP 8     /* main fast instantiation: 5120 or 6144 samples (0 = chosen by batch)  */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

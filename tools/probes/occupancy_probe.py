@@ -21,7 +21,9 @@ eng = DemuxEngine(np.zeros((10, K)), 15, 0.1, sig_proc.SegParams(barcode_num_eve
 eng.ctx.set_option(_lib.OPT_DEBUG_OCCUPANCY, 1)
 sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, n)
 a_e = torch.minimum(a_e, a_s + 3800)
-for ml in (4096, 6144, 4096, 6144):
+for ml, force, pcap in ((4096, 0, 0), (5120, 5120, 0), (5120, 5120, 976), (5120, 5120, 920), (6144, 6144, 0), (5120, 5120, 976)):
+    eng.ctx.set_option(_lib.OPT_FAST_MAIN_CAP, force)
+    eng.ctx.set_option(_lib.OPT_FAST_PEAK_CAP, pcap)
     ts = []
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,5 +33,5 @@ for ml in (4096, 6144, 4096, 6144):
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
         eng.ctx.set_option(_lib.OPT_DEBUG_OCCUPANCY, 0)
-    print(f"max_len {ml}: {min(ts):.2f} ms for {n} reads  ok={int((out[3] == 0).sum())}")
+    print(f"max_len {ml} forced main {force} peak cap {pcap}: {min(ts):.2f} ms for {n} reads  ok={int((out[3] == 0).sum())}")
     eng.ctx.set_option(_lib.OPT_DEBUG_OCCUPANCY, 1)

@@ -28,6 +28,7 @@ K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE = 0, 1, 2, 3, 4, 5
 # wdx_ctx_set_option selectors (diagnostics; the product path leaves all of them 0)
 OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBUG_OCCUPANCY, OPT_FAST_PEAK_CAP = 1, 2, 3, 4, 5, 6
 OPT_FAST_EXACT_SCORES = 7
+OPT_FAST_MAIN_CAP = 8
 COMM_ID_BYTES = 128
 ABI_VERSION = 2
 

@@ -1210,7 +1210,8 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
     return WDX_SUCCESS;
 }
 
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 8 * (n_reads > 0 ? n_reads : 0); }
+// four counters + four read lists (slow, big0, big1, retry: see launch_fingerprint)
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 16 * (n_reads > 0 ? n_reads : 0); }
 
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
@@ -1244,7 +1245,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, knobs.fast_exact_scores ? 1 : 0, RefineDev{}};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, 1, RefineDev{}};
     if (rf) {
         if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
             set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,
@@ -1273,59 +1274,133 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                          p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
                          !knobs.exact_path && !rf;
     if (fast_ok) {
-        // samples per thread: the smaller instantiation when the longest adapter window allows it;
-        // windows beyond 6144 samples take the slow path
-        const bool small_fast = cap <= 4096;
-        const int capF = small_fast ? 4096 : 6144;
-        // peak-list capacity: local maxima of the score curve run at ~N/5.6 (>= N/5.0 observed); N/4.4
-        // leaves headroom and keeps four workgroups per CU resident at 6144 samples (five at 4096); a
-        // read with more peaks takes the slow path.  (A 5120-sample instantiation at five workgroups
-        // per CU for the 89 % of reads that fit it was measured: no gain, the kernel is issue-bound
-        // from four workgroups on.)
-        int capP = small_fast ? 1152 : 1376;
+        // A chain of launches, each handing what it cannot take to the next through device-side lists:
+        //   main    one workgroup per read; the instantiation follows the longest adapter window of the batch:
+        //           4096 or (large batches) 5120 samples at FIVE workgroups per CU, else 6144 at four.  A fifth
+        //           resident workgroup is worth 1.16x (tools/probes/occupancy_probe.py); 89 % of RNA004 adapter
+        //           windows fit 5120 samples
+        //   big0    windows (and peak lists) beyond the main instantiation -> 6144-sample list kernel
+        //   big1    beyond that -> 8192-sample list kernel (three workgroups per CU)
+        //   retry   reads whose approximate score keys left an order decision inside the error band (about 2 in
+        //           1000) -> 8192-sample list kernel with exact scores
+        //   slow    everything else (NaNs, other window widths, long plateaus, ...) -> the exact general kernel
+        // Small batches (live ticks) skip the approximate keys, and with them the retry launch, and go straight
+        // to the 6144-sample instantiation: there a launch costs more than the arithmetic saved.
+        // Peak-list capacities: local maxima of the score curve run at ~N/5.6 (>= N/5.0 observed); the capacities
+        // leave headroom within the LDS budget of the instantiation's occupancy; overflows move up the chain.
+        constexpr int64_t kFastChainMinReads = 2048;
+        const bool large_batch = n_reads >= kFastChainMinReads;
+        const bool approx = large_batch && !knobs.fast_exact_scores;
+        int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
+        if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
+        // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
+        // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
+        int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP);
-        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow list, [1] big list
+        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
-        int32_t *big = list + n_reads;
+        int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads;
         WDX_HIP_TRY(hipMemsetAsync(count, 0, 16, stream));
-        // windows of 6145..8192 samples (and reads whose peak lists overflow) are listed on the device and
-        // retried by an 8192-sample instantiation (three workgroups per CU) before anything takes the
-        // exact slow path; only launched when the batch can contain such windows
-        const bool with_big = !small_fast && cap > 6144 && !(d_prof && stop_phase > 0);
-        FastArgs F{A, capF, capP, count, list, with_big ? count + 1 : nullptr, with_big ? big : nullptr, nullptr, nullptr};
+        const bool chain = !(d_prof && stop_phase > 0);         // (ablation timing: the main kernel alone)
+        const bool with_big0 = chain && capF == 5120;            // windows of 5121..6144 samples, peak-list overflows
+        const bool with_big1 = chain && capF >= 5120 && cap > 6144;  // windows of 6145..8192 samples
+        A.exact_scores = approx ? 0 : 1;
+        FastArgs F{A, capF, capP, count, list, nullptr, nullptr, nullptr, nullptr, 0u, approx ? count + 3 : nullptr,
+                   approx ? retry : nullptr};
+        if (with_big0) {
+            F.big_count = count + 1;
+            F.big_list = big0;
+        } else if (with_big1) {
+            F.big_count = count + 2;
+            F.big_list = big1;
+        }
         void (*kern)(FastArgs) = nullptr;
-        if (d_prof) kern = small_fast ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptLarge, true>;
-        else kern = small_fast ? fingerprint_fast_kernel<kNptSmall, false> : fingerprint_fast_kernel<kNptLarge, false>;
-        static LdsAttr attr_fast[4];
-        if (int rc = attr_fast[(d_prof ? 2 : 0) + (small_fast ? 1 : 0)].ensure(kern, flds)) return rc;
+        int slot = 0;
+        if (capF == 4096) {
+            kern = d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>;
+        } else if (capF == 5120) {
+            kern = d_prof ? fingerprint_fast_kernel<kNptMid, true> : fingerprint_fast_kernel<kNptMid, false>;
+            slot = 1;
+        } else {
+            kern = d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>;
+            slot = 2;
+        }
+        static LdsAttr attr_fast[6];
+        if (int rc = attr_fast[(d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
-            fprintf(stderr, "[wdx] fast kernel capF=%d capP=%d lds=%zu B -> %d workgroups/CU\n", capF, capP, flds, nb);
+            fprintf(stderr, "[wdx] fast kernel capF=%d capP=%d lds=%zu B -> %d workgroups/CU%s\n", capF, capP, flds, nb,
+                    approx ? ", approximate score keys" : "");
         }
-        // grid.x * block.x must stay below 2^32: equal launch slices of at most 2^31 / FB reads
-        const int64_t max_slice = (1ll << 31) / FB, n_slices = (n_reads + max_slice - 1) / max_slice;
-        const int64_t slice = (n_reads + n_slices - 1) / n_slices;
-        for (int64_t base = 0; base < n_reads; base += slice) {
-            const int64_t n = n_reads - base < slice ? n_reads - base : slice;
-            F.a.block_base = base;
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(FB), flds, stream, F);
-            if (n_launches) ++*n_launches;
-        }
-        if (with_big) {
-            const int capF2 = 8192, capP2 = 1856;
-            const size_t flds2 = fast_lds_bytes(capF2, capP2);
-            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big};
-            static LdsAttr attr_huge;
+        // one workgroup per read (or list entry); grid.x * block.x must stay below 2^32: equal launch slices of at
+        // most 2^31 / FB workgroups
+        auto launch_sliced = [&](void (*k)(FastArgs), FastArgs &fa, int64_t n_wg, size_t lds_bytes, bool counted) {
+            const int64_t max_slice = (1ll << 31) / FB, n_slices = (n_wg + max_slice - 1) / max_slice;
+            const int64_t slice = (n_wg + n_slices - 1) / n_slices;
+            for (int64_t base = 0; base < n_wg; base += slice) {
+                const int64_t n = n_wg - base < slice ? n_wg - base : slice;
+                fa.a.block_base = base;
+                hipLaunchKernelGGL(k, dim3((unsigned)n), dim3(FB), lds_bytes, stream, fa);
+                if (counted && n_launches) ++*n_launches;
+            }
+        };
+        launch_sliced(kern, F, n_reads, flds, true);
+        // the list kernels
+        const int64_t grid = n_reads < 1024 ? n_reads : 1024;  // striding kernels: every CU busy, nothing more
+        const int capF1 = 6144, capP1 = 1376, capF2 = 8192, capP2 = 1856;
+        const size_t flds1 = fast_lds_bytes(capF1, capP1), flds2 = fast_lds_bytes(capF2, capP2);
+        static LdsAttr attr_l1, attr_huge;
+        if (with_big0 || (approx && chain))
+            if (int rc = attr_l1.ensure(fingerprint_fast_list1_kernel<kNptLarge>, flds1)) return rc;
+        if (with_big0 || with_big1 || (approx && chain))
             if (int rc = attr_huge.ensure(fingerprint_fast_list_kernel<kNptHuge>, flds2)) return rc;
-            const int64_t grid = n_reads < 1024 ? n_reads : 1024;
+        if (with_big0) {
+            // 11 % of RNA004 adapter windows are longer than 5120 samples: a grid for a quarter of the batch, one
+            // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
+            const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
+            FastArgs F1{A, capF1, capP1, count, list, with_big1 ? count + 2 : nullptr, with_big1 ? big1 : nullptr,
+                        count + 1, big0, 0u, F.retry_count, F.retry_list};
+            launch_sliced(fingerprint_fast_list1_kernel<kNptLarge>, F1, g1, flds1, false);
+            if (g1 < n_reads) {
+                FastArgs F1b{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big0, (unsigned)g1, F.retry_count,
+                             F.retry_list};
+                hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2,
+                                   stream, F1b);
+            }
+        }
+        if (with_big1) {
+            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list};
             hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2, stream,
                                F2);
         }
+        if (approx && chain) {
+            // about 2 reads in 1000: a grid for 1/64 of the batch on the 6144-sample instantiation with exact scores
+            // (a window beyond 6144 samples moves on to the slow path), the striding kernel beyond
+            const int64_t g3 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 64));
+            FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr};
+            F3.a.exact_scores = 1;
+            launch_sliced(fingerprint_fast_list1_kernel<kNptLarge>, F3, g3, flds1, false);
+            if (g3 < n_reads) {
+                FastArgs F3b{F3.a, capF2, capP2, count, list, nullptr, nullptr, count + 3, retry, (unsigned)g3, nullptr,
+                             nullptr};
+                hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2,
+                                   stream, F3b);
+            }
+        }
         WDX_HIP_TRY(hipGetLastError());
-        return small ? launch_fp_list<512>(A, lds, count, list, stream)
-                     : launch_fp_list<1024>(A, lds, count, list, stream);
+        if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
+                           : launch_fp_list<1024>(A, lds, count, list, stream))
+            return rc;
+        if (knobs.debug_occ) {  // (diagnostic: synchronises)
+            unsigned c[4] = {0, 0, 0, 0};
+            WDX_HIP_TRY(hipMemcpyAsync(c, count, 16, hipMemcpyDeviceToHost, stream));
+            WDX_HIP_TRY(hipStreamSynchronize(stream));
+            fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u beyond 6144 samples, %u redone with "
+                            "exact scores, %u on the exact general kernel\n", (long long)n_reads, c[1], c[2], c[3], c[0]);
+        }
+        return WDX_SUCCESS;
     }
     return small ? launch_fp_chunks<512, false>(A, lds, stream, n_launches)
                  : launch_fp_chunks<1024, false>(A, lds, stream, n_launches);
