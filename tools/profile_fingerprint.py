@@ -32,7 +32,9 @@ ok = status.cpu().numpy() == 0
 declined = int(p[0, 15]) if fast else 0
 if fast:
     dec = p[p[:, 9] == 0]
-    print("decline reasons (0 gate,1 NaN,2 inexact,3 plateau/cap,4 nbr,5 kept cap,6 tie):", np.bincount(dec[:, 13].astype(int), minlength=7).tolist())
+    print("handed on by the main kernel (0 window beyond its capacity / parameter gate, 1 NaN, 2 sums not provably exact, "
+          "3 plateau / peak-list capacity, 4 nbr, 5 kept-list capacity, 6 tie at the top-E cut, 7 doubt -> exact-scores retry):",
+          np.bincount(dec[:, 13].astype(int), minlength=8).tolist())
 if fast:
     names = ["P0 load", "P1a median", "P1b MAD+clip", "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E",
              "P5 boundaries", "P6 event means", "P7 normalise"]
@@ -49,7 +51,8 @@ for i in range(9):
 print("  suppression iterations: median %d  p99 %d  max %d" % (np.median(p[:, 10]), np.percentile(p[:, 10], 99), p[:, 10].max()))
 print("  n samples median %d, score positions median %d" % (np.median(p[:, 11]), np.median(p[:, 12])))
 if fast:
-    print("  attempts of P2..P4 (1 = approximate keys sufficed):", np.bincount(p[:, 14].astype(int), minlength=3).tolist())
+    print("  score mode of the reads the main kernel finished (1 = approximate keys, 2 = exact scores):",
+          np.bincount(p[:, 14].astype(int), minlength=3).tolist())
 
 if fast:
     q = p[:, 16:23]

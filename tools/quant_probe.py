@@ -21,5 +21,5 @@ for name, data in (("adc 0.1755 pA", np.round(mb / scale).astype(np.float32) * s
     dec = p[p[:, 9] == 0]
     print(name, "declined", int(p[0, 15]), "of", n, "reasons", np.bincount(dec[:, 13].astype(int), minlength=7).tolist(), "status", np.bincount(status.cpu().numpy(), minlength=6).tolist())
     fin = p[p[:, 9] != 0]
-    print("   attempts of P2..P4:", np.bincount(fin[:, 14].astype(int), minlength=3).tolist())
+    print("   score mode (1 = approximate keys, 2 = exact scores):", np.bincount(fin[:, 14].astype(int), minlength=3).tolist())
     eng.close()

@@ -114,6 +114,17 @@ Timed::Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
         }
     }
     (void)hipEventRecord(ev.first, s);
+    if (id == WDX_K_FINGERPRINT) {  // a second pair for the main fast-kernel launches (recorded by launch_fingerprint)
+        std::pair<hipEvent_t, hipEvent_t> m{nullptr, nullptr};
+        if (!c->pool.empty()) {
+            m = c->pool.back();
+            c->pool.pop_back();
+        } else if (hipEventCreate(&m.first) != hipSuccess || hipEventCreate(&m.second) != hipSuccess) {
+            m = {nullptr, nullptr};
+        }
+        main.first = m.first;
+        main.second = m.second;
+    }
 }
 
 Timed::~Timed() {
@@ -121,6 +132,14 @@ Timed::~Timed() {
     (void)hipEventRecord(ev.second, s);
     c->pending[id].push_back(ev);
     c->pending_launches[id].push_back(n_launches > 0 ? n_launches : 1);
+    if (main.first) {
+        if (main.recorded) {
+            c->pending[WDX_K_FINGERPRINT_MAIN].push_back({main.first, main.second});
+            c->pending_launches[WDX_K_FINGERPRINT_MAIN].push_back(n_launches > 0 ? n_launches : 1);
+        } else {
+            c->pool.push_back({main.first, main.second});
+        }
+    }
 }
 
 int check_ctx(wdx_ctx *ctx) {
@@ -486,7 +505,8 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
     Timed t(ctx, WDX_K_FINGERPRINT, (hipStream_t)stream);
     return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                               d_a_end, d_ok, *p, d_fpt, d_dwell, d_stats, d_status,
-                              (hipStream_t)stream, ctx->fp_ws.p, ctx->knobs, &t.n_launches);
+                              (hipStream_t)stream, ctx->fp_ws.p, ctx->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
+                              &t.main);
 }
 
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
@@ -687,7 +707,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
         Timed t(ctx, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                                      d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s, fp_ws,
-                                     ctx->knobs, &t.n_launches)))
+                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, nullptr, &t.main)))
             return rc;
     }
     if (rowmajor) {

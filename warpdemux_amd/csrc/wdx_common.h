@@ -100,13 +100,20 @@ int fill_refine_dev(const wdx_refine_params &rp, const double *d_query, int32_t 
 void free_refine_dev(struct RefineDev *rf);
 
 // ---- fingerprint (wdx_fingerprint.hip) ---------------------------------------------------------
+// Optional event pair recorded around the launches of the MAIN fast kernel only (WDX_K_FINGERPRINT_MAIN): the
+// fingerprint stage is a chain of launches, and the roofline is quoted on its dominant kernel.
+struct MainEvents {
+    hipEvent_t first = nullptr, second = nullptr;
+    bool recorded = false;
+};
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
                        const Knobs &knobs, int64_t *n_launches = nullptr, long long *d_prof = nullptr,
-                       int64_t prof_reads = 0, int stop_phase = 0, const struct RefineDev *rf = nullptr);
+                       int64_t prof_reads = 0, int stop_phase = 0, const struct RefineDev *rf = nullptr,
+                       MainEvents *main_ev = nullptr);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
 int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream);
 

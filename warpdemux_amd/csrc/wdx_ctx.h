@@ -23,7 +23,7 @@ struct PinnedBuffer {  // grow-only page-locked host staging area
     void release();
 };
 
-constexpr int kNumTimed = 6;
+constexpr int kNumTimed = 7;
 
 // RAII: make the context's device current for the duration of one entry point and put the caller's
 // device back afterwards (a host thread that also drives torch must not find its device switched).
@@ -73,6 +73,7 @@ struct Timed {  // RAII: hipEvents around one kernel launch when timing is on
     hipStream_t s;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     int64_t n_launches = 0;  // kernel launches bracketed by this event pair (0 -> counted as 1)
+    MainEvents main;         // WDX_K_FINGERPRINT only: a second pair around the main fast-kernel launches alone
     Timed(wdx_ctx *c_, int id_, hipStream_t s_);
     ~Timed();
 };

@@ -1218,7 +1218,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws, const Knobs &knobs, int64_t *n_launches,
-                       long long *d_prof, int64_t prof_reads, int stop_phase, const RefineDev *rf) {
+                       long long *d_prof, int64_t prof_reads, int stop_phase, const RefineDev *rf,
+                       MainEvents *main_ev) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (n_reads > 0x7fffffffLL) {
         set_error("at most 2^31-1 reads per call");
@@ -1346,7 +1347,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                 if (counted && n_launches) ++*n_launches;
             }
         };
+        if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         launch_sliced(kern, F, n_reads, flds, true);
+        if (main_ev && main_ev->first) {
+            (void)hipEventRecord(main_ev->second, stream);
+            main_ev->recorded = true;
+        }
         // the list kernels
         const int64_t grid = n_reads < 1024 ? n_reads : 1024;  // striding kernels: every CU busy, nothing more
         const int capF1 = 6144, capP1 = 1376, capF2 = 8192, capP2 = 1856;
@@ -1390,6 +1396,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             }
         }
         WDX_HIP_TRY(hipGetLastError());
+        if (!chain) return WDX_SUCCESS;  // (ablation timing of the main kernel: the lists are left unprocessed)
         if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
                            : launch_fp_list<1024>(A, lds, count, list, stream))
             return rc;
