@@ -267,6 +267,13 @@ def _option(opt, value, device=None):
         ctx.set_option(opt, 0)
 
 
+def _chain(device=None):
+    """The launch chain of large batches (5120-sample main kernel on approximate score keys -> 6144-sample list
+    kernel -> 8192-sample list kernel -> exact-scores retry -> exact general kernel) for a batch of any size
+    (by default batches below 2048 reads take one 6144-sample launch with exact scores)."""
+    return _option(_lib.OPT_FAST_CHAIN_MIN_READS, 1, device)
+
+
 def test_banded_score_keys_match_exact_scores_and_oracle():
     """The fast kernel takes its order decisions (local maxima, suppression, top-E cut) on approximate score keys and
     only outside an error band; anything inside the band is redone from the reference's exact scores.  The result
@@ -293,9 +300,10 @@ def test_banded_score_keys_match_exact_scores_and_oracle():
     for name, data in cases.items():
         for K in (25, 110):
             ph = sig_proc.SegParams(barcode_num_events=K)
-            a = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
-            with _option(_lib.OPT_FAST_EXACT_SCORES, 1):
-                b = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
+            with _chain():
+                a = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
+                with _option(_lib.OPT_FAST_EXACT_SCORES, 1):
+                    b = sig_proc.fingerprint_batch(data, a_s, a_e, ph)
             assert np.array_equal(a.status, b.status), name
             assert _same(a.fpt, b.fpt) and _same(a.dwell, b.dwell) and _same(a.stats, b.stats), name
             fpt, dwell, stats, status = orc.fingerprint_batch(data, a_s, a_e, orc.SegParams(barcode_num_events=K))
@@ -317,7 +325,11 @@ def test_adc_quantised_signals_match_oracle():
     coarse = np.round(mb / np.float32(2.0)).astype(np.float32) * np.float32(2.0)
     for data in (q, coarse):
         for K in (25, 110):
+            with _chain():  # approximate keys: every tie is a doubt (tile fall-back / exact-scores retry)
+                fc = sig_proc.fingerprint_batch(data, a_s, a_e, sig_proc.SegParams(barcode_num_events=K))
             fb = sig_proc.fingerprint_batch(data, a_s, a_e, sig_proc.SegParams(barcode_num_events=K))
+            assert np.array_equal(fc.status, fb.status) and _same(fc.fpt, fb.fpt) and _same(fc.dwell, fb.dwell)
+            assert _same(fc.stats, fb.stats)
             fpt, dwell, stats, status = orc.fingerprint_batch(data, a_s, a_e, orc.SegParams(barcode_num_events=K))
             assert np.array_equal(fb.status, status)
             good = status == 0
@@ -795,6 +807,14 @@ def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch)
         assert np.array_equal(fb.status, status) and np.array_equal(sl.status, status) and (status == 0).all()
         assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats)
         assert _same(sl.fpt, fpt) and _same(sl.dwell, dwell) and _same(sl.stats, stats)
+        # the launch chain of large batches: 5120-sample main kernel -> 6144 list kernel -> 8192 list kernel -> retry
+        # -> exact kernel, also with peak lists too small for most reads (everything moves up the chain) and with
+        # a one-entry grid of the per-entry list kernels (everything beyond it goes to the striding kernel)
+        for peak_cap in (0, 600):
+            with _chain(), _option(_lib.OPT_FAST_PEAK_CAP, peak_cap):
+                ch = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+            assert np.array_equal(ch.status, status)
+            assert _same(ch.fpt, fpt) and _same(ch.dwell, dwell) and _same(ch.stats, stats)
 
 
 _RANDOMISED_OK = []
@@ -853,6 +873,10 @@ def test_fingerprint_randomised_configs_and_signal_styles(seed):
     fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po, ok=ok)
     assert np.array_equal(fb.status, status), (kw, np.flatnonzero(fb.status != status))
     assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats), kw
+    with _chain():  # the same batch through the launch chain of large batches (approximate score keys, lists, retry)
+        ch = sig_proc.fingerprint_batch(mb, a_s, a_e, ph, success=ok)
+    assert np.array_equal(ch.status, status), (kw, np.flatnonzero(ch.status != status))
+    assert _same(ch.fpt, fpt) and _same(ch.dwell, dwell) and _same(ch.stats, stats), kw
     # (some parameter draws fail every read in the reference too -- statuses are compared above; the draws
     # as a whole must exercise the success path)
     _RANDOMISED_OK.append(int((status == 0).sum()))

@@ -29,6 +29,7 @@ K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE, K_FINGERPRINT_MAIN 
 OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBUG_OCCUPANCY, OPT_FAST_PEAK_CAP = 1, 2, 3, 4, 5, 6
 OPT_FAST_EXACT_SCORES = 7
 OPT_FAST_MAIN_CAP = 8
+OPT_FAST_CHAIN_MIN_READS = 9
 COMM_ID_BYTES = 128
 ABI_VERSION = 2
 

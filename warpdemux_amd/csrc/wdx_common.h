@@ -29,6 +29,7 @@ struct Knobs {
     bool svm_scalar = false;    // WDX_OPT_SVM_SCALAR
     bool debug_occ = false;     // WDX_OPT_DEBUG_OCCUPANCY
     int fast_peak_cap = 0;      // WDX_OPT_FAST_PEAK_CAP (0 = built-in capacity)
+    int fast_chain_min = 0;     // WDX_OPT_FAST_CHAIN_MIN_READS: batch size from which the launch chain is used (0 = 2048)
     int fast_main_cap = 0;      // WDX_OPT_FAST_MAIN_CAP: 5120 / 6144 forces the main fast instantiation (0 = by batch)
     bool fast_exact_scores = false;  // WDX_OPT_FAST_EXACT_SCORES: fast fingerprint kernel without the approximate first attempt
 };

@@ -1289,8 +1289,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // to the 6144-sample instantiation: there a launch costs more than the arithmetic saved.
         // Peak-list capacities: local maxima of the score curve run at ~N/5.6 (>= N/5.0 observed); the capacities
         // leave headroom within the LDS budget of the instantiation's occupancy; overflows move up the chain.
-        constexpr int64_t kFastChainMinReads = 2048;
-        const bool large_batch = n_reads >= kFastChainMinReads;
+        const int64_t chain_min = knobs.fast_chain_min > 0 ? knobs.fast_chain_min : 2048;
+        const bool large_batch = n_reads >= chain_min;
         const bool approx = large_batch && !knobs.fast_exact_scores;
         int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
         if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
