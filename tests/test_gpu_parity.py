@@ -591,10 +591,18 @@ def test_device_synth_matches_numpy_and_fused_pipeline():
     assert np.array_equal(counts, exp) and counts.sum() == n
     acc = (call[good] == bc.cpu().numpy()[good]).mean()
     assert acc > 0.7, acc   # sanity only: nearest-template accuracy on the synthetic barcodes
-    # second call accumulates into the same histogram
+    # second call accumulates into the same histogram; with timing on, the main fast kernel's event pair (the
+    # roofline's denominator) lies inside the one around the whole fingerprint chain (n >= 2048: main kernel, list
+    # kernels, exact-scores retry, exact general kernel)
+    eng.kernel_time_reset()
+    eng.kernel_timing(True)
     res2 = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, counts=res.counts)
     torch.cuda.synchronize()
+    eng.kernel_timing(False)
     assert np.array_equal(res2.counts.cpu().numpy(), 2 * exp)
+    chain_ms, chain_n = eng.kernel_time(_lib.K_FINGERPRINT)
+    main_ms, main_n = eng.kernel_time(_lib.K_FINGERPRINT_MAIN)
+    assert chain_n == 1 and main_n == 1 and 0.0 < main_ms <= chain_ms
     eng.close()
 
 
