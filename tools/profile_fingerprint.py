@@ -51,6 +51,9 @@ for i in range(9):
 print("  suppression iterations: median %d  p99 %d  max %d" % (np.median(p[:, 10]), np.percentile(p[:, 10], 99), p[:, 10].max()))
 print("  n samples median %d, score positions median %d" % (np.median(p[:, 11]), np.median(p[:, 12])))
 if fast:
+    fb = p[:, 25]
+    print("  wave tiles that fell back to exact scores: %.2f per read on average (%.1f %% of the reads have one; max %d)"
+          % (fb.mean(), 100.0 * (fb > 0).mean(), fb.max()))
     print("  score mode of the reads the main kernel finished (1 = approximate keys, 2 = exact scores):",
           np.bincount(p[:, 14].astype(int), minlength=3).tolist())
 
