@@ -825,6 +825,47 @@ def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch)
             assert _same(ch.fpt, fpt) and _same(ch.dwell, dwell) and _same(ch.stats, stats)
 
 
+def test_launch_chain_lists_longer_than_their_grids():
+    """The per-entry list kernels are launched with grids sized for the expected share of a batch (a quarter for
+    windows beyond the main instantiation, 1/64 -- at least 1024 -- for exact-score retries); entries beyond the grid
+    belong to the striding 8192-sample kernel.  A batch in which EVERY window is longer than 5120 samples, and one in
+    which every read is redone with exact scores (samples on a coarse 2 pA grid: ties everywhere), must still match
+    the oracle read for read."""
+    rng = np.random.default_rng(77)
+    n, stride = 4608, 6000
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    lens = rng.integers(5200, 5900, n)
+    for i, ln in enumerate(lens):
+        ev = int(rng.integers(25, 55))
+        lvl = np.repeat(rng.normal(85, 14, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = (lvl + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = lens.astype(np.int32)
+    ph, po = sig_proc.SegParams(padding=0, barcode_num_events=25), orc.SegParams(padding=0, barcode_num_events=25)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    sub = np.arange(0, n, 9)  # the oracle on every ninth read (all grid / beyond-grid positions of the list occur)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb[sub], a_s[sub], a_e[sub], po)
+    assert np.array_equal(fb.status[sub], status) and (status == 0).mean() > 0.98
+    assert _same(fb.fpt[sub], fpt) and _same(fb.dwell[sub], dwell) and _same(fb.stats[sub], stats)
+    with _exact_path():
+        sl = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    assert np.array_equal(fb.status, sl.status) and _same(fb.fpt, sl.fpt) and _same(fb.dwell, sl.dwell)
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    mb2, a_s2, a_e2, _ = synth.generate_minibatch(spec, 55_000, 2560, 9000)
+    coarse = np.round(mb2 / np.float32(2.0)).astype(np.float32) * np.float32(2.0)
+    fc = sig_proc.fingerprint_batch(coarse, a_s2, a_e2, sig_proc.SegParams(barcode_num_events=110))
+    with _option(_lib.OPT_FAST_EXACT_SCORES, 1):
+        fe = sig_proc.fingerprint_batch(coarse, a_s2, a_e2, sig_proc.SegParams(barcode_num_events=110))
+    assert np.array_equal(fc.status, fe.status) and _same(fc.fpt, fe.fpt) and _same(fc.dwell, fe.dwell)
+    sub = np.arange(0, 2560, 7)
+    fpt, dwell, stats, status = orc.fingerprint_batch(coarse[sub], a_s2[sub], a_e2[sub], orc.SegParams(barcode_num_events=110))
+    assert np.array_equal(fc.status[sub], status)
+    good = status == 0
+    assert good.mean() > 0.95
+    assert _same(fc.fpt[sub][good], fpt[good]) and _same(fc.dwell[sub][good], dwell[good])
+
+
 _RANDOMISED_OK = []
 
 
