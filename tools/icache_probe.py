@@ -7,7 +7,7 @@ reads = sys.argv[1] if len(sys.argv) > 1 else "1000000"
 d = os.path.join(ROOT, "gpurun_out", "icache")
 os.makedirs(d, exist_ok=True)
 cmd = ["rocprofv3", "--kernel-trace", "--pmc", *C, "--output-format", "csv", "-d", d, "--", sys.executable,
-       os.path.join(ROOT, "bench.py"), "--reads", reads, "--steps", "1", "--warmup", "0", "--no-cpu"]
+       os.path.join(ROOT, "bench.py"), "--reads", reads, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-secondary"]
 with open(os.path.join(d, "run.log"), "w") as fh:
     subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=fh, stderr=subprocess.STDOUT, check=False)
 acc = {}
