@@ -866,6 +866,34 @@ def test_launch_chain_lists_longer_than_their_grids():
     assert _same(fc.fpt[sub][good], fpt[good]) and _same(fc.dwell[sub][good], dwell[good])
 
 
+def test_window_lengths_at_every_capacity_and_chunk_edge():
+    """Windows exactly at, one below and one above every instantiation's capacity, at multiples of the 1024-sample
+    step that sets a thread's chunk of the event-mean prefix sums (where the last thread owns a full chunk or the
+    thread after the end owns nothing), and at the fast path's minimum -- single launch and launch chain vs oracle."""
+    rng = np.random.default_rng(4242)
+    lens = [256, 257, 260, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 4095, 4096, 4097, 5116, 5119, 5120, 5121, 5124,
+            6143, 6144, 6145, 7168, 8191, 8192, 8193]
+    lens = lens * 3
+    n, stride = len(lens), 8400
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, ln in enumerate(lens):
+        ev = int(rng.integers(14, 40))
+        lvl = np.repeat(rng.normal(90, 16, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = (lvl + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array(lens, dtype=np.int32)
+    for num_events in (6, 24):   # (a 256-sample window must still hold num_events events)
+        kw = dict(padding=0, num_events=num_events, barcode_num_events=num_events, min_obs_per_base=3)
+        ph, po = sig_proc.SegParams(**kw), orc.SegParams(**kw)
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
+        assert (status == 0).mean() > 0.9
+        for ctx in (contextlib.nullcontext(), _chain()):
+            with ctx:
+                fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+            assert np.array_equal(fb.status, status)
+            assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats)
+
+
 _RANDOMISED_OK = []
 
 
