@@ -1,0 +1,102 @@
+"""Stage-B pin: the oracle DTW against the KKT conditions of the reference's five shipped DTW_SVM models.
+
+The models were trained by libsvm on exp(-D) with D = dtaidistance's own distance matrix of `_X`
+(models/dtw_svm.py:21-22, parallel_distances.py:59-67, 139-198), so their dual coefficients only satisfy
+libsvm's optimality conditions (tests/helpers/kkt.py) under the distances the genuine library returned.
+Fixture g9 (tests/golden/make_golden_kkt.py) holds the models' numbers; nothing here needs /root/reference.
+
+What this pins, at which resolution (measured, `<model>__residuals` in g9):
+* oracle DTW with the model's own (window=15, penalty=0.1): all ~23 000 free-vector equalities hold to
+  5.3-5.6e-4 in each of the five models -- inside libsvm's eps = 1e-3, i.e. as well as the genuine
+  distances themselves do;
+* every structural alternative violates them by >= 17x that: un-squared penalty (0.57), penalty 0
+  (0.10), no final sqrt (1.5), band one cell narrower / wider (0.05 / 0.04), window 5 (0.98), unbanded
+  (0.03-0.43), penalty +-10 % (0.02);
+* a uniform relative bias of 1e-4 moves the residual by ~2.5e-4, so systematic deviations above ~2e-4
+  relative are excluded; per-pair rounding-level differences (1e-7, float32 output) are below its
+  resolution -- those are covered by the bit-exact HIP == oracle tests.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import kkt
+from oracle import wdx_oracle as orc
+
+G9 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_kkt_models.npz")
+EPS = kkt.EPS_LIBSVM
+
+
+@pytest.fixture(scope="module")
+def g9():
+    return np.load(G9)
+
+
+def oracle_dtw(X, window, penalty):
+    return orc.dtw_matrix(X, X, window, penalty)
+
+
+@pytest.mark.parametrize("name", ["WDX4", "WDX4b", "WDX4c", "WDX6", "WDX10"])
+def test_oracle_dtw_satisfies_the_shipped_models_kkt_conditions(g9, name):
+    m = kkt.model_from_npz(g9, name)
+    assert (m["window"], m["penalty"], m["gamma"], m["pwr_dist"]) == (15, 0.1, 1.0, 1)
+    D = oracle_dtw(m["X"], m["window"], m["penalty"])
+    r = kkt.kkt_residuals(D, m["n_support"], m["dual_coef"], m["intercept"], m["c_bound"], m["gamma"], m["pwr_dist"])
+    assert r["n_free"] > 1800 and r["n_bound"] > 200 and r["n_zero"] > 1100
+    assert r["free_max_abs"] < EPS, r          # 0 < alpha < C : y f(x) = 1 within libsvm's eps
+    assert r["bound_max"] < EPS, r             # alpha = C     : y f(x) <= 1
+    assert r["zero_min"] > -EPS, r             # alpha = 0     : y f(x) >= 1
+    # and the numbers recorded when the fixture was made (same oracle, same model)
+    ref = g9[f"{name}__residuals"][list(g9["variant_names"]).index("reference")]
+    assert np.allclose([r["free_max_abs"], r["bound_max"], r["zero_min"]], ref, rtol=0, atol=1e-9)
+
+
+CONTROLS = ["penalty_not_squared", "penalty_zero", "no_final_sqrt", "window_minus_1", "window_plus_1",
+            "window_5", "unbanded", "penalty_plus_10pct", "penalty_minus_10pct"]
+
+
+@pytest.mark.parametrize("name", ["WDX4", "WDX6"])
+def test_negative_controls_violate_the_kkt_conditions(g9, name):
+    """The test has teeth: each single change to the recurrence breaks the conditions by >= 17 eps."""
+    m = kkt.model_from_npz(g9, name)
+    vs = kkt.variants(oracle_dtw, m["X"], m["window"], m["penalty"])
+    for vn in CONTROLS:
+        r = kkt.kkt_residuals(vs[vn](), m["n_support"], m["dual_coef"], m["intercept"], m["c_bound"], m["gamma"], m["pwr_dist"])
+        assert kkt.worst(r) > 17 * EPS, (vn, r)
+
+
+def test_recorded_controls_of_every_model(g9):
+    """All five models' recorded residuals (make_golden_kkt.py): reference variant inside eps, every
+    control outside by >= 17 eps, and the 1e-4 uniform scaling still inside (the stated resolution)."""
+    names = list(g9["variant_names"])
+    for name in g9["models"]:
+        res = g9[f"{name}__residuals"]
+        w = np.maximum(np.maximum(res[:, 0], res[:, 1]), -res[:, 2])
+        assert w[names.index("reference")] < 0.6 * EPS
+        for vn in CONTROLS:
+            assert w[names.index(vn)] > 17 * EPS, (name, vn)
+        assert w[names.index("reference")] < w[names.index("scaled_1e-4")] < EPS
+
+
+# ---- dtaidistance's published examples (documentation, "DTW between set of series"; stated from the docs
+# of 2.3.x as the builder knows them -- the pages are not fetchable here, so these are anchors, not pins) ----
+
+def test_documented_distance_matrix_example():
+    s = [np.array([0.0, 0, 1, 2, 1, 0, 1, 0, 0]), np.array([0.0, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0]),
+         np.array([0.0, 0, 1, 2, 1, 0, 0, 0])]                 # unequal lengths 9 / 11 / 8
+    got = np.array([[orc.dtw_distance(a, b) for b in s] for a in s])
+    want = np.array([[0, 1.41421356, 1.0], [1.41421356, 0, 1.0], [1.0, 1.0, 0]])
+    assert np.allclose(got, want, rtol=0, atol=5e-9)
+
+
+def test_documented_block_example():
+    """`distance_matrix_fast(series, block=((1, 4), (3, 5)))` of the six-series example: rows 1..3 x
+    columns 3..4, upper triangle only -- the call shape parallel_distances.py:34-43 uses."""
+    base = [[0.0, 0, 1, 2, 1, 0, 1, 0, 0], [0.0, 1, 2, 0, 0, 0, 0, 0, 0], [1.0, 2, 0, 0, 0, 0, 0, 1, 1]]
+    s = np.array(base + base)
+    D = orc.dtw_matrix(s[1:4], s[3:5])
+    printed = {(1, 3): 1.4142, (1, 4): 0.0, (2, 3): 2.2360, (2, 4): 1.7320, (3, 4): 1.4142}   # the docs print 4 digits, truncated
+    for (r, c), v in printed.items():
+        assert abs(float(D[r - 1, c - 3]) - v) < 1e-4
+    assert D[1, 0] == np.float32(np.sqrt(5.0)) and D[1, 1] == np.float32(np.sqrt(3.0))
