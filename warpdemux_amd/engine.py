@@ -111,12 +111,20 @@ class DemuxEngine:
             self._stream()))
         return fpt, dwell, stats, status
 
-    def dtw(self, X, want_argmin=True):
-        """Device DTW of (n, L) float64 rows against the resident refs."""
+    def dtw(self, X, want_argmin=True, out=None):
+        """Device DTW of (n, L) float64 rows against the resident refs.  ``out=(dist, argmin)`` reuses the
+        caller's device tensors (float32 (n, nY), int32 (n,) or None) instead of allocating."""
         torch = self.torch
         n = int(X.shape[0])
-        dist = torch.empty((n, self.nY), dtype=torch.float32, device=self.tdev)
-        am = torch.empty(n, dtype=torch.int32, device=self.tdev) if want_argmin else None
+        if out is not None:
+            dist, am = out
+            if tuple(dist.shape) != (n, self.nY) or dist.dtype != torch.float32 or not dist.is_contiguous():
+                raise ValueError("out[0] must be a contiguous float32 (n, nY) device tensor")
+            if am is not None and (tuple(am.shape) != (n,) or am.dtype != torch.int32):
+                raise ValueError("out[1] must be an int32 (n,) device tensor")
+        else:
+            dist = torch.empty((n, self.nY), dtype=torch.float32, device=self.tdev)
+            am = torch.empty(n, dtype=torch.int32, device=self.tdev) if want_argmin else None
         _lib.check(self.L.wdx_dtw_matrix_dev(self.ctx.handle, _dp(X), n, _dp(dist), _dp(am), self._stream()))
         return dist, am
 
