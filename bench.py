@@ -480,6 +480,10 @@ def run_rank(args):
         k, v = kv.split("=")
         eng.ctx.set_option(int(k), int(v))
     reducer = dist.CountReducer(eng.ctx, prefer="torch" if host_collectives else None)
+    if world > 1 and not host_collectives and reducer.mode != "rccl":
+        # the multi-GPU figure must be the C ABI's RCCL road; anything else is a configuration to fix, not to time
+        raise SystemExit(f"bench.py: rank {rank}: --gpus {world} ended on the '{reducer.mode}' road ({reducer.note}); "
+                         "set WDX_BENCH_BACKEND=gloo to time the process-group fallback on purpose")
 
     # ---- the global read range and this rank's contiguous shard of it ----------------------------
     per_gpu = args.reads or (10_000_000 if world == 1 else 5_000_000)
@@ -631,6 +635,7 @@ def run_rank(args):
                 "count_allreduce": {"single": "none (one process)", "rccl": "wdx_reduce_counts (C ABI, RCCL)",
                                     "torch": "torch.distributed.all_reduce (%s)" % (backend or "nccl")}[reducer.mode]
                                    + (("; " + reducer.note) if reducer.note else ""),
+                "rccl_ranks": reducer.rccl_ranks,     # ncclCommCount of the C ABI's communicator (null: no communicator)
             },
             "roofline": {
                 "bound": "hbm",

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WDX_ABI_VERSION 2
+#define WDX_ABI_VERSION 3
 
 /* ---- call status ------------------------------------------------------------------------- */
 #define WDX_SUCCESS 0
@@ -93,8 +93,10 @@ int wdx_device_count(void);
 /* Create a context on HIP device `device`.  First HIP use in the process happens here. */
 int wdx_ctx_create(int device, wdx_ctx **out);
 void wdx_ctx_destroy(wdx_ctx *ctx);
-/* Block until all work enqueued through this context on `stream` (NULL = the context's own stream)
- * has finished. */
+/* Block until all work enqueued on `stream` has finished.  stream == NULL names the legacy NULL stream,
+ * exactly as in the *_dev entry points, AND the context's own stream (wdx_ctx_stream) is waited for too --
+ * so `wdx_demux_dev(..., NULL); wdx_ctx_synchronize(ctx, NULL);` is complete when it returns (ABI 2 briefly
+ * waited for the context stream only: fixed in ABI 3). */
 int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream);
 /* The context's own stream (hipStream_t as void*): the one its host-buffer calls run on. */
 int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
@@ -269,12 +271,20 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
  * librccl is dlopen'ed on first use (the copy already loaded in the process, e.g. PyTorch's, is
  * preferred), so a single-GPU user never needs it. */
 #define WDX_COMM_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+/* WDX_SUCCESS when librccl could be bound in this process, WDX_ERR_NO_DEVICE (and the reason in
+ * wdx_last_error) when it could not.  Local and cheap: every rank asks BEFORE anyone enters the collective
+ * wdx_comm_init, so that all ranks take the same road.  Needs no context. */
+int wdx_comm_available(void);
 /* Rank 0 creates the rendezvous id and hands the 128 bytes to the other ranks by any means (the
  * launcher's store, a file, MPI ...).  Needs no context. */
 int wdx_comm_unique_id(void *id_out /* WDX_COMM_ID_BYTES */);
 /* Collective over all `world` ranks: bind the context to rank `rank` of the communicator `id`. */
 int wdx_comm_init(wdx_ctx *ctx, const void *id, int32_t rank, int32_t world);
 int wdx_comm_destroy(wdx_ctx *ctx);
+/* What the context is bound to: rank/world as given to wdx_comm_init (0 / 1 without a communicator) and
+ * rccl_count = the rank count RCCL itself reports for the communicator (ncclCommCount; 0 without a
+ * communicator, -1 if this librccl lacks the query).  Outputs nullable. */
+int wdx_comm_info(wdx_ctx *ctx, int32_t *rank, int32_t *world, int32_t *rccl_count);
 /* In-place SUM all-reduce of d_counts int64[n] (DEVICE pointer, e.g. wdx_demux_dev's d_counts) over the
  * communicator, enqueued on `stream`; no synchronisation.  Without a communicator (single process) it is
  * a no-op that returns WDX_SUCCESS. */

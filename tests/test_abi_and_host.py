@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     L = _lib.load()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.wdx_abi_version() == 2
+    assert L.wdx_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_seg_params_struct_layout_matches_header():

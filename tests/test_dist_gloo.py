@@ -89,6 +89,74 @@ def test_two_rank_count_allreduce():
     assert np.array_equal(np.bincount(call, minlength=5), g0)
 
 
+def _fallback_worker(rank, world, port, scenario, out_q):
+    """prefer="rccl" on a gloo group with the RCCL step failing in a controlled way on ONE rank: the
+    collectives of all ranks must still match (no hang) and every rank must end on the same road."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    from warpdemux_amd import _lib, dist
+
+    dist.init_process_group("gloo")
+
+    class Reducer(dist.CountReducer):
+        def _rccl_unavailable(self):
+            self._L = None
+            if scenario == "rank0_unavailable" and rank == 0:
+                return "[wdx -2] RCCL unavailable: librccl not found (test)"
+            if scenario == "rank1_unavailable" and rank == 1:
+                return "[wdx -2] RCCL unavailable: librccl not found (test)"
+            return ""
+
+        def _draw_id(self):
+            raise _lib.WdxError("[wdx -3] ncclGetUniqueId failed (test)")
+
+    class FakeCtx:          # only its presence matters before wdx_comm_init
+        handle = None
+
+    counts = torch.tensor([rank + 1, 10 * (rank + 1)], dtype=torch.int64)
+    try:
+        red = Reducer(FakeCtx(), prefer="rccl")
+        red(counts)
+        out_q.put((rank, red.mode, red.note, counts.tolist(), None))
+    except Exception as e:  # noqa: BLE001
+        out_q.put((rank, "raised", "", counts.tolist(), f"{type(e).__name__}: {e}"))
+    dist.barrier()          # the groups' collectives still line up after the failure path
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("scenario", ["rank0_unavailable", "rank1_unavailable", "rank0_id_error"])
+def test_rccl_failure_paths_do_not_hang_and_agree(scenario):
+    """rank 0 failing before the id broadcast used to leave the other ranks waiting in it, and any
+    exception became a silent torch.distributed run.  Now: RCCL missing (WDX_ERR_NO_DEVICE) on any rank ->
+    ALL ranks use the process group and say so; any other failure is raised on EVERY rank."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, scenario, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if scenario.endswith("unavailable"):
+        for rank, mode, note, counts, err in res:
+            assert err is None and mode == "torch" and "torch.distributed used on all ranks" in note
+            assert counts == [3, 30]
+        culprit = 0 if scenario.startswith("rank0") else 1
+        assert "this rank" in res[culprit][2] and "another rank" in res[1 - culprit][2]
+    else:
+        for rank, mode, note, counts, err in res:
+            assert mode == "raised" and "rank 0 could not create the RCCL id" in err and "ncclGetUniqueId failed" in err
+            assert counts == [rank + 1, 10 * (rank + 1)]
+
+
 def test_single_process_helpers_are_noops():
     import torch
 

@@ -241,7 +241,13 @@ def test_rccl_count_reduction_through_the_c_abi():
     counts = torch.arange(11, dtype=torch.int64, device="cuda") * 1000003
     # no communicator: a no-op that succeeds
     _lib.check(L.wdx_reduce_counts(ctx.handle, C.c_void_p(counts.data_ptr()), 11, None))
+    assert L.wdx_comm_available() == 0
+    r, w, cnt = C.c_int32(-9), C.c_int32(-9), C.c_int32(-9)
+    _lib.check(L.wdx_comm_info(ctx.handle, C.byref(r), C.byref(w), C.byref(cnt)))
+    assert (r.value, w.value, cnt.value) == (0, 1, 0)          # no communicator yet
     _lib.check(L.wdx_comm_init(ctx.handle, ident, 0, 1))
+    _lib.check(L.wdx_comm_info(ctx.handle, C.byref(r), C.byref(w), C.byref(cnt)))
+    assert (r.value, w.value, cnt.value) == (0, 1, 1)          # RCCL's own count (ncclCommCount)
     s = torch.cuda.current_stream().cuda_stream
     _lib.check(L.wdx_reduce_counts(ctx.handle, C.c_void_p(counts.data_ptr()), 11, C.c_void_p(s)))
     torch.cuda.synchronize()
@@ -252,6 +258,30 @@ def test_rccl_count_reduction_through_the_c_abi():
     with pytest.raises(ValueError):
         _lib.check(L.wdx_comm_init(ctx.handle, ident, 3, 2))
     _lib.check(L.wdx_comm_destroy(ctx.handle))
+    ctx.close()
+
+
+def test_ctx_synchronize_null_names_the_null_stream_and_the_context_stream():
+    """`wdx_demux_dev(..., NULL); wdx_ctx_synchronize(ctx, NULL)` must be complete on return (ABI 3)."""
+    import torch
+
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    nX, nY, K = 200_000, 64, 25
+    Y = rng.normal(size=(nY, K))
+    ctx = _lib.Context(0)
+    _lib.check(L.wdx_set_refs(ctx.handle, _lib.ptr(Y), nY, K, 15, 0.1))
+    X = torch.from_numpy(rng.normal(size=(nX, K))).cuda()
+    d = torch.full((nX, nY), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(L.wdx_dtw_matrix_dev(ctx.handle, C.c_void_p(X.data_ptr()), nX, C.c_void_p(d.data_ptr()), None, None))
+    _lib.check(L.wdx_ctx_synchronize(ctx.handle, None))
+    # a D2H on a DIFFERENT non-blocking stream does not wait for the NULL stream: it sees finished results only if
+    # the synchronise above really waited
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        tail = d[-64:].to("cpu", non_blocking=False)
+    assert (tail.numpy() >= 0).all()
     ctx.close()
 
 

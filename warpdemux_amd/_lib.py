@@ -31,14 +31,14 @@ OPT_FAST_EXACT_SCORES = 7
 OPT_FAST_MAIN_CAP = 8
 OPT_FAST_CHAIN_MIN_READS = 9
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 
 # every symbol include/wdx.h declares (tests check the .so exports each of them)
 EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
-    "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_unique_id", "wdx_comm_init",
+    "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_available", "wdx_comm_info", "wdx_comm_unique_id", "wdx_comm_init",
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
     "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
@@ -106,6 +106,10 @@ class WdxError(RuntimeError):
     pass
 
 
+class WdxNoDevice(WdxError):
+    """WDX_ERR_NO_DEVICE: no usable HIP device / runtime / RCCL in this process."""
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -166,6 +170,10 @@ def load():
         L.wdx_ctx_stream.argtypes = [vp, P(vp)]
         L.wdx_ctx_set_option.restype = C.c_int
         L.wdx_ctx_set_option.argtypes = [vp, i32, i64]
+        L.wdx_comm_available.restype = C.c_int
+        L.wdx_comm_available.argtypes = []
+        L.wdx_comm_info.restype = C.c_int
+        L.wdx_comm_info.argtypes = [vp, P(i32), P(i32), P(i32)]
         L.wdx_comm_unique_id.restype = C.c_int
         L.wdx_comm_unique_id.argtypes = [vp]
         L.wdx_comm_init.restype = C.c_int
@@ -235,6 +243,8 @@ def check(rc: int):
         raise ValueError(msg)
     if rc == WDX_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == WDX_ERR_NO_DEVICE:
+        raise WdxNoDevice(f"[wdx {rc}] {msg}")
     raise WdxError(f"[wdx {rc}] {msg}")
 
 

@@ -421,8 +421,16 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream) {
 
 int wdx_ctx_synchronize(wdx_ctx *ctx, void *stream) {
     WDX_ENTER(ctx);
-    // NULL = the context's own stream (the one every host-buffer call runs on)
-    WDX_HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    // NULL names the legacy NULL stream, as in every *_dev entry point (engine.py hands over torch's default
+    // stream, whose handle is 0).  The context's own non-blocking stream -- the one the host-buffer calls run
+    // on -- is waited for as well: those calls synchronise before they return, so this costs nothing and a
+    // caller who only knows the context cannot be handed a half-finished result.
+    if (stream) {
+        WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    } else {
+        WDX_HIP_TRY(hipStreamSynchronize(nullptr));
+        WDX_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     return WDX_SUCCESS;
 }
 
@@ -478,6 +486,7 @@ int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, i
     if ((rc = ctx->in0.ensure(xb))) return rc;
     if ((rc = ctx->out0.ensure(ob))) return rc;
     if (argmin && (rc = ctx->out1.ensure((size_t)nX * sizeof(int32_t)))) return rc;
+    StreamDrain drain(s);
     WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X, xb, hipMemcpyHostToDevice, s));
     if ((rc = dtw_dev_locked(ctx, (const double *)ctx->in0.p, nX, (float *)ctx->out0.p,
                              argmin ? (int32_t *)ctx->out1.p : nullptr, s)))
@@ -487,6 +496,7 @@ int wdx_dtw_matrix(wdx_ctx *ctx, const double *X, int64_t nX, const double *Y, i
         WDX_HIP_TRY(hipMemcpyAsync(argmin, ctx->out1.p, (size_t)nX * sizeof(int32_t),
                                    hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipStreamSynchronize(s));
+    drain.done();
     return WDX_SUCCESS;
 }
 
@@ -591,6 +601,7 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
         RefineDev *&r;
         ~RfGuard() { free_refine_dev(r); }
     } rf_guard{rf};
+    StreamDrain drain(s);
     if (rp) {
         // [query doubles | idx int32 (n,3)] on the device; idx starts as -1 (reads that fail before the match)
         const size_t qb = ((size_t)rp->n_query * 8 + 15) / 16 * 16;
@@ -635,6 +646,7 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
                                    hipMemcpyDeviceToHost, s));
     }
     WDX_HIP_TRY(hipStreamSynchronize(s));
+    drain.done();
     return WDX_SUCCESS;
 }
 
@@ -782,6 +794,7 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     if ((rc = ctx->out2.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    StreamDrain drain(s);
     // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
     // file_proc.py:244-260; the kernels never read outside [start, stop))
     if (col1 > col0)
@@ -812,6 +825,7 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     WDX_HIP_TRY(hipMemcpyAsync(status, ctx->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
     if (fpt) WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipStreamSynchronize(s));
+    drain.done();
     if (R.nY == 0)
         for (int64_t r = 0; r < n_reads; ++r) call[r] = -1;
     return WDX_SUCCESS;
@@ -931,6 +945,7 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
     if ((rc = ctx->out1.ensure((size_t)chunk * k * 8))) return rc;
     if ((rc = ctx->out2.ensure((size_t)chunk * 4))) return rc;
     if ((rc = ctx->out3.ensure((size_t)chunk * 8))) return rc;
+    StreamDrain drain(s);
     for (int64_t r0 = 0; r0 < n; r0 += chunk) {
         const int64_t m = std::min(chunk, n - r0);
         WDX_HIP_TRY(hipMemcpyAsync(ctx->in0.p, X + r0 * R.L, (size_t)(m * R.L) * 8, hipMemcpyHostToDevice, s));
@@ -946,6 +961,7 @@ int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, 
         if (conf) WDX_HIP_TRY(hipMemcpyAsync(conf + r0, ctx->out3.p, (size_t)m * 8, hipMemcpyDeviceToHost, s));
     }
     WDX_HIP_TRY(hipStreamSynchronize(s));
+    drain.done();
     return WDX_SUCCESS;
 }
 

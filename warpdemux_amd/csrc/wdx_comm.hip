@@ -30,6 +30,8 @@ struct Rccl {
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional: what RCCL itself says the world is
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;   // optional
     bool ok = false;
     char why[256] = "";
 };
@@ -52,6 +54,8 @@ Rccl &rccl() {
         R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.handle, "ncclCommDestroy");
         R.AllReduce = (decltype(R.AllReduce))dlsym(R.handle, "ncclAllReduce");
         R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.handle, "ncclGetErrorString");
+        R.CommCount = (decltype(R.CommCount))dlsym(R.handle, "ncclCommCount");
+        R.CommUserRank = (decltype(R.CommUserRank))dlsym(R.handle, "ncclCommUserRank");
         R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllReduce && R.GetErrorString;
         if (!R.ok) snprintf(R.why, sizeof(R.why), "librccl lacks an expected entry point");
     });
@@ -95,6 +99,29 @@ void comm_destroy(wdx_ctx *ctx) {
 using namespace wdx;
 
 extern "C" {
+
+int wdx_comm_available(void) { return rccl_ready(); }
+
+int wdx_comm_info(wdx_ctx *ctx, int32_t *rank, int32_t *world, int32_t *rccl_count) {
+    WDX_ENTER(ctx);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int32_t r = 0, w = 1, cnt = 0;
+    if (ctx->comm) {
+        r = ctx->comm->rank;
+        w = ctx->comm->world;
+        cnt = -1;
+        int v = 0;
+        if (rccl().CommCount && rccl().CommCount(ctx->comm->comm, &v) == kNcclSuccess) cnt = v;
+        if (rccl().CommUserRank && rccl().CommUserRank(ctx->comm->comm, &v) == kNcclSuccess && v != r) {
+            set_error("comm_info: RCCL reports rank %d, the context was bound as rank %d", v, r);
+            return WDX_ERR_HIP;
+        }
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (rccl_count) *rccl_count = cnt;
+    return WDX_SUCCESS;
+}
 
 int wdx_comm_unique_id(void *id_out) {
     if (!id_out) {

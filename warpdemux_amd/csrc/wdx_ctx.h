@@ -96,6 +96,20 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 }  // namespace wdx
 
+// Host-buffer entry points enqueue copies from/to the CALLER's (or the context's page-locked) memory and
+// synchronise once at the end.  A failure half way must not return while such a copy may still be in flight
+// (the caller frees or rewrites its buffers; PinnedBuffer::ensure may hipHostFree the staging block on the next
+// call): every exit of the enqueue region drains the stream unless the normal final synchronisation already ran.
+struct StreamDrain {
+    hipStream_t s;
+    bool armed = true;
+    explicit StreamDrain(hipStream_t s_) : s(s_) {}
+    void done() { armed = false; }
+    ~StreamDrain() {
+        if (armed) (void)hipStreamSynchronize(s);  // best effort: the error already recorded is the one reported
+    }
+};
+
 #define WDX_ENTER(ctx)                                  \
     if (int _e = ::wdx::check_ctx(ctx)) return _e;      \
     ::wdx::DeviceGuard _guard((ctx)->device);           \

@@ -793,6 +793,14 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *s
     if (P.seg_norm == WDX_NORM_MEAN) { shift = mean; scale = sd; }
     else if (P.seg_norm == WDX_NORM_MEDIAN) { shift = ev_med; scale = ev_mad; }
     else { finish(WDX_READ_FAIL_UNKNOWN, false); return; }  // "none" is not a normalize_wrt method: ValueError
+    // The final status is decided first and stats / indices are written ONCE: "consensus query outlier" and
+    // success report them, the nseg2 < K "unknown" path (the np.pad call subtracts an int from a tuple ->
+    // TypeError) reports NaN / -1 -- no second write to the same addresses by other lanes.
+    const bool outlier = qs > R.ub_start || qe < R.lb_end || qe > R.ub_end;
+    if (!outlier && nseg2 < K) {
+        finish(WDX_READ_FAIL_UNKNOWN, false);
+        return;
+    }
     if (tid == 0) {
         if (A.stats) {
             double *o = A.stats + r * 6;
@@ -802,12 +810,8 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *s
             R.idx[r * 3] = qs; R.idx[r * 3 + 1] = qe; R.idx[r * 3 + 2] = sbs;
         }
     }
-    if (qs > R.ub_start || qe < R.lb_end || qe > R.ub_end) {
+    if (outlier) {
         finish(WDX_READ_FAIL_CONSENSUS, true);  // "consensus query outlier": stats and indices are reported
-        return;
-    }
-    if (nseg2 < K) {  // the np.pad call subtracts an int from a tuple -> TypeError -> "unknown"
-        finish(WDX_READ_FAIL_UNKNOWN, false);
         return;
     }
     for (int i = tid; i < K; i += BLOCK) {

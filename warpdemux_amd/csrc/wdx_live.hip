@@ -111,6 +111,7 @@ int wdx_live_tick(wdx_ctx *ctx, const float *const *rows, const int32_t *row_len
     unsigned char *din = (unsigned char *)ctx->in0.p, *dout = (unsigned char *)ctx->out0.p;
     unsigned char *hout = (unsigned char *)ctx->pin_out.p;
 
+    StreamDrain drain(s);
     WDX_HIP_TRY(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, s));
     {
         Timed t(ctx, WDX_K_FINGERPRINT, s);
@@ -143,6 +144,7 @@ int wdx_live_tick(wdx_ctx *ctx, const float *const *rows, const int32_t *row_len
     if (fpt) lo = std::min(lo, q_fpt);
     WDX_HIP_TRY(hipMemcpyAsync(hout + lo, dout + lo, hi - lo, hipMemcpyDeviceToHost, s));
     WDX_HIP_TRY(hipStreamSynchronize(s));
+    drain.done();
     memcpy(status, hout + q_status, b_status);
     if (call) {
         if (R.nY > 0) memcpy(call, hout + q_call, b_call);

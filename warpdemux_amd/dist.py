@@ -65,7 +65,18 @@ class CountReducer:
     already initialised torch.distributed group (any side channel would do).  ``mode == "torch"``:
     ``torch.distributed.all_reduce`` on the process group (gloo in the CPU tests; nccl = RCCL too).
     ``mode == "single"``: one process, nothing to do.  ``prefer`` = "rccl" | "torch" | None (rccl when
-    the group's backend is nccl and the engine is on a GPU)."""
+    the group's backend is nccl and the engine is on a GPU).
+
+    Every rank takes the same road, decided BEFORE anyone enters a collective of the C ABI:
+    1. each rank asks ``wdx_comm_available()`` (local) and the answers meet in a MIN all-reduce on the
+       process group -- if librccl cannot be bound on ANY rank (WDX_ERR_NO_DEVICE) ALL ranks use
+       torch.distributed, and ``note`` says why;
+    2. rank 0 draws the id; the broadcast ALWAYS runs -- an error on rank 0 travels in it and is raised
+       on every rank (nobody is left waiting in the broadcast);
+    3. ``wdx_comm_init`` (collective); any failure there is a real RCCL fault and is raised, never
+       turned into a silent torch.distributed run;
+    4. ``rccl_ranks`` = what RCCL itself reports for the communicator (``ncclCommCount``) must equal
+       the world size."""
 
     def __init__(self, ctx=None, prefer: str | None = None):
         import torch.distributed as dist
@@ -73,40 +84,72 @@ class CountReducer:
         self.ctx = ctx
         self.mode = "single"
         self.note = ""
+        self.rccl_ranks = None
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
         self.mode = "torch"
+        if prefer not in (None, "rccl", "torch"):
+            raise ValueError("prefer must be 'rccl', 'torch' or None")
         want_rccl = prefer == "rccl" or (prefer is None and dist.get_backend() == "nccl")
-        if want_rccl and ctx is not None:
-            try:
-                self._init_rccl(dist)
-                self.mode = "rccl"
-            except Exception as e:  # noqa: BLE001 -- fall back to the process group, and say so
-                self.note = f"wdx_comm_init unavailable ({type(e).__name__}: {e}); torch.distributed used"
-        # every rank must take the same road
+        if not (want_rccl and ctx is not None):
+            return
         import torch
 
-        flag = torch.tensor([1 if self.mode == "rccl" else 0], dtype=torch.int32,
+        why = self._rccl_unavailable()
+        flag = torch.tensor([0 if why else 1], dtype=torch.int32,
                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if self.mode == "rccl" and int(flag.item()) == 0:
-            self._L.wdx_comm_destroy(self.ctx.handle)
-            self.mode = "torch"
+        if int(flag.item()) == 0:
+            self.note = ("RCCL not bindable on %s (%s); torch.distributed used on all ranks"
+                         % ("this rank" if why else "another rank", why or "see that rank's note"))
+            return
+        self._init_rccl(dist)
+        self.mode = "rccl"
+
+    def _rccl_unavailable(self) -> str:
+        """'' when this process can bind librccl, else the reason (only WDX_ERR_NO_DEVICE counts as
+        'unavailable'; anything else is raised)."""
+        from . import _lib
+
+        self._L = _lib.load()
+        try:
+            _lib.check(self._L.wdx_comm_available())
+        except _lib.WdxNoDevice as e:
+            return str(e)
+        return ""
+
+    def _draw_id(self) -> bytes:
+        import ctypes as C
+
+        from . import _lib
+
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(self._L.wdx_comm_unique_id(buf))
+        return bytes(buf.raw)
 
     def _init_rccl(self, dist):
         import ctypes as C
 
         from . import _lib
 
-        self._L = L = _lib.load()
         rank, world = dist.get_rank(), dist.get_world_size()
-        ident = [None]
+        box = [None]
         if rank == 0:
-            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
-            _lib.check(L.wdx_comm_unique_id(buf))
-            ident[0] = bytes(buf.raw)
-        dist.broadcast_object_list(ident, src=0)
-        _lib.check(L.wdx_comm_init(self.ctx.handle, ident[0], rank, world))
+            try:
+                box[0] = ("id", self._draw_id())
+            except Exception as e:  # noqa: BLE001 -- travels to every rank in the broadcast below, raised there
+                box[0] = ("error", f"{type(e).__name__}: {e}")
+        dist.broadcast_object_list(box, src=0)
+        kind, payload = box[0]
+        if kind != "id":
+            raise _lib.WdxError(f"rank 0 could not create the RCCL id: {payload}")
+        _lib.check(self._L.wdx_comm_init(self.ctx.handle, payload, rank, world))
+        r, w, cnt = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        _lib.check(self._L.wdx_comm_info(self.ctx.handle, C.byref(r), C.byref(w), C.byref(cnt)))
+        if (r.value, w.value) != (rank, world) or cnt.value not in (world, -1):
+            raise _lib.WdxError(f"RCCL communicator reports {cnt.value} ranks (bound as rank {r.value} of {w.value}); "
+                                f"the process group has {world}")
+        self.rccl_ranks = cnt.value
 
     def __call__(self, counts, stream=None):
         """counts: int64 torch tensor (device tensor for "rccl"); reduced in place."""
