@@ -159,7 +159,10 @@ int wdx_fingerprint_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64
  *   d_row_len == NULL  -> row_len[r] = d_row_off ? d_row_off[r+1]-d_row_off[r] : stride
  * (so a packed batch passes int64 offsets[n_reads+1] and NULL lengths).  max_len bounds the
  * adapter window of every read (it sizes the LDS carve-up); windows longer than max_len or than
- * the kernel's on-chip capacity WDX_MAX_ADAPTER_SAMPLES are reported WDX_READ_FAIL_UNKNOWN.
+ * WDX_MAX_ADAPTER_SAMPLES are reported WDX_READ_FAIL_UNKNOWN.  (The largest window the reference admits is
+ * max_obs_trace + 2*padding = 15 200 samples, DEPRECATED/config_files/rna002_70bps@v0.4.4.toml:2; up to 11 200
+ * samples a read's score curve lives in LDS, beyond that in a context-owned HBM block of 32 MiB that is
+ * allocated on first need -- a synchronising hipMalloc on that one call.)
  * Any output pointer except d_status may be NULL. */
 int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                         const int32_t *d_row_len, int64_t stride, int64_t max_len,
@@ -167,7 +170,7 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                         const uint8_t *d_ok, const wdx_seg_params *p, double *d_fpt,
                         int64_t *d_dwell, double *d_stats, int32_t *d_status, void *stream);
 
-#define WDX_MAX_ADAPTER_SAMPLES 11200
+#define WDX_MAX_ADAPTER_SAMPLES 16384
 
 /* ---- N3: consensus-guided barcode refinement (tRNA models) -- detect_results_to_fpt with
  *      segmentation.consensus_refinement = True (sig_proc.py:257-378, 452-521): segment the adapter, find the

@@ -261,6 +261,46 @@ def test_rccl_count_reduction_through_the_c_abi():
     ctx.close()
 
 
+def test_long_adapter_windows_through_live_ticks_and_device_entry_points():
+    """Windows of 11 201 .. 15 200 samples (legal in the reference's RNA002 config, the chemistry the live path
+    serves: live_balancing/worker.py:36-44) through wdx_live_tick, wdx_fingerprint_dev and wdx_demux_dev."""
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    rng = np.random.default_rng(77)
+    lens = [15200, 11201, 13000, 9000, 4000, 15200, 12000, 16384]
+    rows = []
+    for ln in lens:
+        dw = ln // 135
+        rows.append((np.repeat(rng.normal(80, 15, ln // dw + 1), dw)[:ln] + rng.normal(0, 2, ln)).astype(np.float32))
+    kw = dict(padding=0, num_events=110, min_obs_per_base=15, running_stat_width=30, barcode_num_events=25)
+    ph, po = sig_proc.SegParams(**kw), orc.SegParams(**kw)
+    a_s = np.zeros(len(lens), dtype=np.int32)
+    a_e = np.array(lens, dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    packed = np.concatenate(rows)
+    fpt, dwell, stats, status = orc.fingerprint_packed(packed, off, a_s, a_e, po)
+    assert (status == 0).all()
+    Y = rng.normal(size=(6, 25))
+    Dref = orc.dtw_matrix(fpt, Y, 15, 0.1)
+    ld = LiveDemux(Y, 15, 0.1, ph, max_reads=8, max_samples=16384)
+    r = ld.tick(rows, a_s, a_e, want_fpt=True)
+    assert np.array_equal(r.status, status) and np.array_equal(r.fpt, fpt)
+    assert np.array_equal(r.dist.view(np.uint32), Dref.view(np.uint32)) and np.array_equal(r.call, orc.argmin_rows(Dref))
+    ld.close()
+    eng = DemuxEngine(Y, 15, 0.1, ph)
+    d = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    g_fpt, g_dwell, g_stats, g_status = eng.fingerprint(d(packed), d(a_s), d(a_e), offsets=d(off), max_len=max(lens))
+    assert np.array_equal(g_status.cpu().numpy(), status) and np.array_equal(g_fpt.cpu().numpy(), fpt)
+    assert np.array_equal(g_dwell.cpu().numpy(), dwell) and np.array_equal(g_stats.cpu().numpy(), stats)
+    res = eng.demux(d(packed), d(a_s), d(a_e), offsets=d(off), max_len=max(lens), want_fpt=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(res.dist.cpu().numpy().view(np.uint32), Dref.view(np.uint32))
+    assert np.array_equal(res.call.cpu().numpy(), orc.argmin_rows(Dref))
+    eng.close()
+
+
 def test_ctx_synchronize_null_names_the_null_stream_and_the_context_stream():
     """`wdx_demux_dev(..., NULL); wdx_ctx_synchronize(ctx, NULL)` must be complete on return (ABI 3)."""
     import torch

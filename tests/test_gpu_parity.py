@@ -340,11 +340,12 @@ def test_adc_quantised_signals_match_oracle():
 
 
 def test_fingerprint_long_rows_and_capacity():
-    """adapter windows up to the on-chip capacity (1024-thread / one-workgroup-per-CU carve-up)"""
+    """adapter windows up to the exact kernel's LDS capacity (11 200: 1024-thread / one-workgroup-per-CU carve-up),
+    beyond it up to WDX_MAX_ADAPTER_SAMPLES = 16 384 (score curve in the context's HBM block), and past that"""
     rng = np.random.default_rng(12)
-    n, stride = 6, 14000
+    n, stride = 9, 17000
     mb = np.full((n, stride), np.nan, dtype=np.float32)
-    lens = [11200, 11000, 9000, 11201, 14000, 7000]
+    lens = [11200, 11000, 9000, 11201, 14000, 7000, 16384, 16385, 17000]
     for i, ln in enumerate(lens):
         mb[i, :ln] = (np.repeat(rng.normal(80, 15, ln // 40 + 1), 40)[:ln] + rng.normal(0, 2, ln)).astype(np.float32)
     a_s = np.zeros(n, dtype=np.int32)
@@ -353,11 +354,75 @@ def test_fingerprint_long_rows_and_capacity():
     fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
     fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, po)
     for i, ln in enumerate(lens):
-        if ln > 11200:
-            assert fb.status[i] == 5   # documented engine limit (WDX_MAX_ADAPTER_SAMPLES)
+        if ln > 16384:
+            assert fb.status[i] == 5   # documented engine limit (WDX_MAX_ADAPTER_SAMPLES); the reference's configs stop at 15 200
+            assert np.isnan(fb.fpt[i]).all() and (fb.dwell[i] == 0).all()
         else:
             assert fb.status[i] == status[i] == 0
             assert _same(fb.fpt[i], fpt[i]) and _same(fb.dwell[i], dwell[i]) and _same(fb.stats[i], stats[i])
+
+
+def test_long_window_golden_vectors(golden_dir):
+    """g4b: the reference's own detect_results_to_fpt on windows of 9 000 .. 15 200 samples, three shipped
+    parameter triples (tests/golden/make_golden_long.py) -- one read per call, all in one batch, and on the
+    exact general kernel."""
+    g = np.load(os.path.join(golden_dir, "g4b_long_windows.npz"))
+    n = int(g["n"])
+    for exact in (False, True):
+        with (_exact_path() if exact else contextlib.nullcontext()):
+            for k in range(n):
+                tag = str(g[f"tag_{k}"])
+                a_start, a_end, ok = (int(v) for v in g[f"args_{k}"])
+                p_hip, _ = _params_from(g, k)
+                fb = sig_proc.fingerprint_batch(g[f"row_{k}"].reshape(1, -1), [a_start], [a_end], p_hip, success=[ok])
+                st_ref = int(g[f"status_{k}"])
+                assert int(fb.status[0]) == st_ref, f"case {k} ({tag}): status {fb.status[0]} != {st_ref}"
+                if st_ref == 0:
+                    assert _same(fb.fpt[0], g[f"fpt_{k}"]), f"case {k} ({tag}) fpt"
+                    assert _same(fb.dwell[0], g[f"dwell_{k}"]), f"case {k} ({tag}) dwell"
+                    assert _same(fb.stats[0], g[f"stats_{k}"]), f"case {k} ({tag}) stats"
+    # the nine plain cases share their parameters per triple: one mixed-length batch per triple
+    for triple in ("rna004", "rna002", "trna"):
+        ks = [k for k in range(n) if str(g[f"tag_{k}"]) in {f"{triple}_{m}" for m in (11201, 13000, 15200)}]
+        assert len(ks) == 3
+        stride = max(g[f"row_{k}"].size for k in ks)
+        mb = np.full((len(ks), stride), np.nan, dtype=np.float32)
+        for i, k in enumerate(ks):
+            mb[i, :g[f"row_{k}"].size] = g[f"row_{k}"]
+        a_s = np.array([int(g[f"args_{k}"][0]) for k in ks], dtype=np.int32)
+        a_e = np.array([int(g[f"args_{k}"][1]) for k in ks], dtype=np.int32)
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, _params_from(g, ks[0])[0])
+        for i, k in enumerate(ks):
+            assert fb.status[i] == 0 and _same(fb.fpt[i], g[f"fpt_{k}"]) and _same(fb.dwell[i], g[f"dwell_{k}"])
+
+
+@pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18)])
+def test_long_windows_in_large_batches_vs_oracle(triple):
+    """3 000 reads whose windows straddle every capacity edge (5 120 / 6 144 / 8 192 / 11 200 / 16 384) through the
+    launch chain: the few beyond 11 200 samples reach fingerprint_big_kernel via the slow list."""
+    E, d, w = triple
+    rng = np.random.default_rng(E + d + w)
+    n = 3000
+    lens = rng.integers(2500, 9000, n)
+    edge = [5119, 5120, 5121, 6144, 6145, 8192, 8193, 11199, 11200, 11201, 11264, 13000, 15200, 16383, 16384, 16385]
+    lens[:len(edge)] = edge
+    lens[100:140] = rng.integers(11201, 16385, 40)
+    stride = int(lens.max())
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, ln in enumerate(lens):
+        dw = max(12, ln // 135)
+        mb[i, :ln] = (np.repeat(rng.normal(80, 15, ln // dw + 1), dw)[:ln] + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = lens.astype(np.int32)
+    kw = dict(padding=0, num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+    big = lens > 16384
+    assert (fb.status[big] == 5).all() and big.sum() == 1
+    assert np.array_equal(fb.status[~big], status[~big])
+    good = (status == 0) & ~big
+    assert good.sum() > 0.95 * n
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good])
 
 
 def test_fingerprint_empty_and_ragged_inputs():

@@ -109,6 +109,26 @@ def test_g4_fingerprint_end_to_end_bit_exact(golden_dir):
     assert {0, 1, 3, 4, 5} <= seen
 
 
+def test_g4b_long_adapter_windows_bit_exact(golden_dir):
+    """Adapter windows of 9 000 .. 15 200 samples (the largest the reference's configs admit) for the three
+    shipped parameter triples, incl. "mean" signal normalisation, float64 clip bounds, a NaN window
+    (tests/golden/make_golden_long.py ran the reference's detect_results_to_fpt on them)."""
+    g = _load(golden_dir, "g4b_long_windows.npz")
+    tags = set()
+    for k in range(int(g["n"])):
+        tag = str(g[f"tag_{k}"])
+        a_start, a_end, ok = (int(v) for v in g[f"args_{k}"])
+        res = orc.fingerprint_one(g[f"row_{k}"], a_start, a_end, _params_from(g, k), ok=bool(ok))
+        st_ref = int(g[f"status_{k}"])
+        assert res["status"] == st_ref, f"case {k} ({tag}): status {res['status']} != {st_ref}"
+        if st_ref == 0:
+            assert _same(res["fpt"], g[f"fpt_{k}"]), f"case {k} ({tag}) fpt"
+            assert _same(res["dwell"], g[f"dwell_{k}"]), f"case {k} ({tag}) dwell"
+            assert _same(res["stats"], g[f"stats_{k}"]), f"case {k} ({tag}) stats"
+        tags.add(tag)
+    assert {"rna004_15200", "rna002_15200", "trna_15200", "rna002_11201", "rna002_15200_nan_middle"} <= tags
+
+
 def test_g4_signorm_median(golden_dir):
     g = _load(golden_dir, "g4_fingerprint.npz")
     hit = 0

@@ -134,6 +134,7 @@ def main():
         return {"reads": total, "mismatching_reads": bad, "ok": not any(bad.values())}
     out["long_6400_8000"] = gate_long(long_reads(6400, 8000, 8000), args.long)
     out["long_8200_11200"] = gate_long(long_reads(8200, 11200, 11200), args.long * 2 // 5)
+    out["long_11201_15200"] = gate_long(long_reads(11201, 15200, 15200), args.long // 5)   # score curve in HBM
     out["all_ok"] = bool(out["r1"]["parity"]["ok"] and out["r2"]["bitwise_equal"] and out["r2"]["argmin_equal"]
                          and all(v["ok"] for k, v in out.items() if isinstance(v, dict) and "ok" in v))
     print(json.dumps(out, indent=1))

@@ -372,7 +372,7 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big})
         b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -513,11 +513,12 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
     std::lock_guard<std::mutex> g(ctx->mu);
     if ((rc = use_stream(ctx, (hipStream_t)stream))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     Timed t(ctx, WDX_K_FINGERPRINT, (hipStream_t)stream);
     return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                               d_a_end, d_ok, *p, d_fpt, d_dwell, d_stats, d_status,
                               (hipStream_t)stream, ctx->fp_ws.p, ctx->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
-                              &t.main);
+                              &t.main, (double *)ctx->fp_big.p);
 }
 
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
@@ -596,6 +597,7 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
     if ((rc = ctx->out2.ensure((size_t)n_reads * 6 * 8))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     RefineDev *rf = nullptr;
     struct RfGuard {
         RefineDev *&r;
@@ -633,7 +635,7 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p,
                                      (double *)ctx->out0.p, (int64_t *)ctx->out1.p,
                                      (double *)ctx->out2.p, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p,
-                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, rf)))
+                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, rf, nullptr, (double *)ctx->fp_big.p)))
             return rc;
     }
     WDX_HIP_TRY(hipMemcpyAsync(fpt, ctx->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
@@ -709,6 +711,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
     if (n_reads == 0) return WDX_SUCCESS;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = use_stream(ctx, s))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     unsigned char *w = (unsigned char *)d_work;
     double *fpt = d_fpt ? d_fpt : (double *)w;
     const bool rowmajor = n_reads >= kRowMajorMinReads;
@@ -720,7 +723,7 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
         Timed t(ctx, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start,
                                      d_a_end, d_ok, *p, fpt, d_dwell, d_stats, d_status, s, fp_ws,
-                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, nullptr, &t.main)))
+                                     ctx->knobs, &t.n_launches, nullptr, 0, 0, nullptr, &t.main, (double *)ctx->fp_big.p)))
             return rc;
     }
     if (rowmajor) {
@@ -794,6 +797,7 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     if ((rc = ctx->out2.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     StreamDrain drain(s);
     // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
     // file_proc.py:244-260; the kernels never read outside [start, stop))
@@ -809,7 +813,8 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
         if ((rc = launch_fingerprint((const float *)ctx->in0.p, nullptr, nullptr, stride, max_len, n_reads,
                                      (const int32_t *)ctx->in1.p, (const int32_t *)ctx->in2.p,
                                      ok ? (const uint8_t *)ctx->in3.p : nullptr, *p, (double *)ctx->out0.p,
-                                     nullptr, nullptr, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p, ctx->knobs, &t.n_launches)))
+                                     nullptr, nullptr, (int32_t *)ctx->out3.p, s, ctx->fp_ws.p, ctx->knobs, &t.n_launches,
+                                     nullptr, 0, 0, nullptr, nullptr, (double *)ctx->fp_big.p)))
             return rc;
     }
     if (R.nY > 0) {

@@ -114,8 +114,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        hipStream_t stream, void *d_ws /* fingerprint_workspace_bytes(n) or null */,
                        const Knobs &knobs, int64_t *n_launches = nullptr, long long *d_prof = nullptr,
                        int64_t prof_reads = 0, int stop_phase = 0, const struct RefineDev *rf = nullptr,
-                       MainEvents *main_ev = nullptr);
+                       MainEvents *main_ev = nullptr,
+                       double *d_big = nullptr /* fingerprint_big_bytes(max_len) bytes, or null */);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
+// device bytes the exact kernel needs for the score curves of windows beyond its LDS capacity (0 when max_len fits)
+int64_t fingerprint_big_bytes(int64_t max_len);
 int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------

@@ -31,6 +31,14 @@ constexpr int kMaxW = 64;        // cap on running_stat_width
 constexpr int kTile = 512;       // t-score tile, positions
 constexpr int kMaxEvents = 253;  // cap on num_events (E + 2 boundaries <= 255)
 constexpr int kSegCap = kMaxEvents + 1;
+// Exact kernel: windows up to kExactLdsCap samples keep their float64 score curve in LDS (12-13 B per sample of the
+// 160 KB); longer ones (up to WDX_MAX_ADAPTER_SAMPLES = kBigCap; the reference's RNA002 config allows
+// max_obs_trace + 2*padding = 15 200, DEPRECATED/config_files/rna002_70bps@v0.4.4.toml:2) run the SAME code with
+// the score curve in a per-workgroup HBM slot (L2-resident: 128 KB per slot) -- fingerprint_big_kernel.
+constexpr int kExactLdsCap = 11200;
+constexpr int kBigCap = WDX_MAX_ADAPTER_SAMPLES;
+constexpr int kBigSlots = 256;  // one workgroup per CU (97 KB of LDS each)
+static_assert(kBigCap % 64 == 0 && kBigCap >= 15200, "the exact path must take every window the reference accepts");
 
 enum : unsigned char { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_DROPPED = 3, ST_SELECTED = 4 };
 
@@ -68,6 +76,8 @@ struct FpArgs {
     int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
     int exact_scores;    // fast kernel: exact t-scores from the first attempt (WDX_OPT_FAST_EXACT_SCORES)
     RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
+    double *big_scores;  // kBigSlots x kBigCap doubles: score curves of windows beyond the LDS capacity (nullable)
+    int defer_big;       // 1: a window beyond `cap` is left to fingerprint_big_kernel (no status written here)
 };
 
 struct alignas(8) FpShared {
@@ -835,16 +845,18 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *s
         }                                                                                   \
     } while (0)
 
-template <int BLOCK, bool PROF>
+template <int BLOCK, bool PROF, bool BIG = false>
 __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char *smem) {
     const int tid = threadIdx.x;
     const wdx_seg_params &P = A.p;
     const int K = P.barcode_num_events;
     const int E = P.num_events;
 
-    // LDS carve-up (every region starts 8-byte aligned; cap is a multiple of 64)
-    double *scores = reinterpret_cast<double *>(smem);                    // cap
-    double *Mt = scores + A.cap;                                          // kTile + kMaxW
+    // LDS carve-up (every region starts 8-byte aligned; cap is a multiple of 64).  BIG: the score curve lives in
+    // this workgroup's HBM slot instead (same code, global loads/stores: the address space follows the
+    // instantiation), everything else stays in LDS.
+    double *scores = BIG ? A.big_scores + (size_t)blockIdx.x * kBigCap : reinterpret_cast<double *>(smem);  // cap
+    double *Mt = BIG ? reinterpret_cast<double *>(smem) : scores + A.cap;  // kTile + kMaxW
     double *Vt = Mt + (kTile + kMaxW);                                    // kTile + kMaxW
     double *ev = Vt + (kTile + kMaxW);                                    // kSegCap
     double *zz = ev + kSegCap;                                            // kSegCap
@@ -890,6 +902,7 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     int64_t n64 = stop - start;
     if (n64 < 0) n64 = 0;
     if (n64 > A.cap) {
+        if (!BIG && A.defer_big && n64 <= kBigCap) return;  // fingerprint_big_kernel takes it
         finish(WDX_READ_FAIL_UNKNOWN);
         return;
     }
@@ -1137,6 +1150,28 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_list_kernel(FpArgs A, const
     }
 }
 
+// windows beyond the LDS capacity of the exact kernel (kExactLdsCap < n <= kBigCap): a fixed grid of <= kBigSlots
+// workgroups strides over the slow list (or over all reads when there is none) and takes only those
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fingerprint_big_kernel(FpArgs A, const unsigned *count, const int32_t *list,
+                                                                int small_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t n = count ? (int64_t)*count : A.n_reads;
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const int64_t r = list ? (int64_t)list[k] : k;
+        if (A.ok && !A.ok[r]) continue;  // the regular kernel reported it
+        const int64_t row_len = A.row_len ? (int64_t)A.row_len[r]
+                                          : (A.row_off ? A.row_off[r + 1] - A.row_off[r] : A.stride);
+        int64_t start = (int64_t)A.a_start[r] - A.p.padding;
+        if (start < 0) start = 0;
+        int64_t stop = (int64_t)A.a_end[r] + A.p.padding;
+        if (stop > row_len) stop = row_len;
+        if (stop - start <= small_cap || stop - start > kBigCap) continue;
+        __syncthreads();
+        fp_process_read<BLOCK, false, true>(A, r, smem);
+    }
+}
+
 #include "wdx_fingerprint_fast.inc"
 
 static size_t fp_lds_bytes(int cap) {
@@ -1150,6 +1185,25 @@ static size_t fp_lds_bytes(int cap) {
     b += (size_t)(kSegCap + 1) * 4;         // cpts
     if (cap > (int)((kTile + kMaxW) * 16)) b += (size_t)cap;  // dedicated state
     return (b + 15) & ~(size_t)15;
+}
+
+static size_t fp_lds_bytes_big(int cap) { return fp_lds_bytes(cap) - (size_t)cap * 8; }  // no score curve in LDS
+
+int64_t fingerprint_big_bytes(int64_t max_len) {
+    return max_len > kExactLdsCap ? (int64_t)kBigSlots * kBigCap * 8 : 0;
+}
+
+static int launch_fp_big(FpArgs A, int small_cap, const unsigned *count, const int32_t *list, hipStream_t stream) {
+    static LdsAttr attr;
+    const size_t lds = fp_lds_bytes_big(kBigCap);
+    if (int rc = attr.ensure(fingerprint_big_kernel<1024>, lds)) return rc;
+    A.cap = kBigCap;
+    A.defer_big = 0;
+    const int64_t grid = A.n_reads < kBigSlots ? A.n_reads : kBigSlots;
+    hipLaunchKernelGGL((fingerprint_big_kernel<1024>), dim3((unsigned)grid), dim3(1024), lds, stream, A, count, list,
+                       small_cap);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
 }
 
 template <int BLOCK, bool PROF>
@@ -1223,7 +1277,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        double *d_fpt, int64_t *d_dwell, double *d_stats, int32_t *d_status,
                        hipStream_t stream, void *d_ws, const Knobs &knobs, int64_t *n_launches,
                        long long *d_prof, int64_t prof_reads, int stop_phase, const RefineDev *rf,
-                       MainEvents *main_ev) {
+                       MainEvents *main_ev, double *d_big) {
     if (n_reads == 0) return WDX_SUCCESS;
     if (n_reads > 0x7fffffffLL) {
         set_error("at most 2^31-1 reads per call");
@@ -1246,11 +1300,16 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         return WDX_ERR_INVALID;
     }
     int64_t cap64 = max_len;
-    if (cap64 > WDX_MAX_ADAPTER_SAMPLES) cap64 = WDX_MAX_ADAPTER_SAMPLES;
+    if (cap64 > kExactLdsCap) cap64 = kExactLdsCap;
     if (cap64 < 64) cap64 = 64;
     int cap = (int)((cap64 + 63) / 64 * 64);
+    // windows of kExactLdsCap+1 .. kBigCap samples: left alone by every launch below and taken by
+    // fingerprint_big_kernel at the end (needs the caller's fingerprint_big_bytes(max_len) buffer; without it they
+    // are reported WDX_READ_FAIL_UNKNOWN as windows beyond WDX_MAX_ADAPTER_SAMPLES always are)
+    const bool with_huge = max_len > kExactLdsCap && d_big != nullptr && !d_prof;
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
-             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, 1, RefineDev{}};
+             p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, 1, RefineDev{},
+             d_big, with_huge ? 1 : 0};
     if (rf) {
         if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
             set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,
@@ -1404,6 +1463,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
                            : launch_fp_list<1024>(A, lds, count, list, stream))
             return rc;
+        if (with_huge)
+            if (int rc = launch_fp_big(A, cap, count, list, stream)) return rc;
         if (knobs.debug_occ) {  // (diagnostic: synchronises)
             unsigned c[4] = {0, 0, 0, 0};
             WDX_HIP_TRY(hipMemcpyAsync(c, count, 16, hipMemcpyDeviceToHost, stream));
@@ -1413,8 +1474,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         }
         return WDX_SUCCESS;
     }
-    return small ? launch_fp_chunks<512, false>(A, lds, stream, n_launches)
-                 : launch_fp_chunks<1024, false>(A, lds, stream, n_launches);
+    if (int rc = small ? launch_fp_chunks<512, false>(A, lds, stream, n_launches)
+                       : launch_fp_chunks<1024, false>(A, lds, stream, n_launches))
+        return rc;
+    if (with_huge) return launch_fp_big(A, cap, nullptr, nullptr, stream);
+    return WDX_SUCCESS;
 }
 
 }  // namespace wdx

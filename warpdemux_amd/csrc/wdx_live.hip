@@ -108,6 +108,7 @@ int wdx_live_tick(wdx_ctx *ctx, const float *const *rows, const int32_t *row_len
     if ((rc = ctx->out0.ensure(out_bytes))) return rc;
     if ((rc = ctx->pin_out.ensure(out_bytes))) return rc;
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     unsigned char *din = (unsigned char *)ctx->in0.p, *dout = (unsigned char *)ctx->out0.p;
     unsigned char *hout = (unsigned char *)ctx->pin_out.p;
 
@@ -118,7 +119,8 @@ int wdx_live_tick(wdx_ctx *ctx, const float *const *rows, const int32_t *row_len
         if ((rc = launch_fingerprint((const float *)(din + o_sig), (const int64_t *)(din + o_off), nullptr, 0,
                                      max_len, n_reads, (const int32_t *)(din + o_zero), (const int32_t *)(din + o_len),
                                      (const uint8_t *)(din + o_ok), *p, (double *)(dout + q_fpt), nullptr, nullptr,
-                                     (int32_t *)(dout + q_status), s, ctx->fp_ws.p, ctx->knobs, &t.n_launches)))
+                                     (int32_t *)(dout + q_status), s, ctx->fp_ws.p, ctx->knobs, &t.n_launches, nullptr, 0,
+                                     0, nullptr, nullptr, (double *)ctx->fp_big.p)))
             return rc;
     }
     if (R.nY > 0) {
