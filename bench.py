@@ -110,6 +110,19 @@ def effective_cores() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
 def _oracle_minibatch(job):
     """One <=1000-read minibatch driven like file_proc.py:418-450: per-read fingerprints, then one
     distance_matrix_to(n_jobs=1) call and the nearest-reference call.  Runs in a worker THREAD (ctypes
@@ -197,6 +210,7 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
         "unit": "reads/s",
         "cores": cores,
         "logical_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": ("first %d reads of the same workload; oracle/wdx_oracle.c (C restatement of sig_proc.py:394-605 + "
                    "dtaidistance's banded DTW) driven as %d-read minibatches like file_proc.py:418-450, one worker thread "
@@ -419,13 +433,14 @@ def secondary_regimes(device):
     return out
 
 
-def make_refs(spec_clean, synth, sig_proc, device=None):
+def make_refs(spec_clean, synth, sig_proc, device=None, n_barcodes=None):
     """Barcode reference fingerprints: one low-noise template read per barcode through the HIP
     fingerprint kernel (host-buffer entry point)."""
     import numpy as np
 
     from warpdemux_amd import _lib
 
+    N_BARCODES = n_barcodes or globals()["N_BARCODES"]   # (tests build the 4-barcode C2 set)
     ids, rid = {}, 0
     while len(ids) < N_BARCODES:
         b = int(synth.read_layout(spec_clean, np.array([rid]))[0][0])

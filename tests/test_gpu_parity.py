@@ -800,7 +800,8 @@ def test_dtw_svm_predict_reference_model_golden():
 
 
 @pytest.mark.gpu
-def test_full_size_properties_one_million_reads():
+@pytest.mark.parametrize("n_bc", [4, 10])     # 4 = BASELINE config 2 exactly (1 M reads, WDX4), 10 = config 3's shape
+def test_full_size_properties_one_million_reads(n_bc):
     """BASELINE config 2 scale (1 M synthetic reads, fused path), through properties that do not need the
     oracle at that size: run-to-run determinism, shard invariance (any split of the reads gives the same
     per-read results and the same count histogram -- what the multi-GPU sharding relies on), a checksum of
@@ -811,9 +812,10 @@ def test_full_size_properties_one_million_reads():
     from bench import make_refs
     from warpdemux_amd.engine import DemuxEngine
 
-    spec = synth.SynthSpec(n_barcodes=10)
+    spec = synth.SynthSpec(n_barcodes=n_bc)
     K, n = 110, 1_000_000
-    refs = make_refs(synth.SynthSpec(n_barcodes=10, noise_sigma=0.25, spikes=False), synth, sig_proc)
+    refs = make_refs(synth.SynthSpec(n_barcodes=n_bc, noise_sigma=0.25, spikes=False), synth, sig_proc, n_barcodes=n_bc)
+    assert refs.shape == (n_bc, K)
     eng = DemuxEngine(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
     sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, n)
     r1 = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, want_fpt=True)
@@ -839,20 +841,25 @@ def test_full_size_properties_one_million_reads():
     ok = r1.status == 0
     assert ok.float().mean().item() > 0.999
     assert (r1.call[ok] == bc[ok]).float().mean().item() > 0.75   # nearest single template, noisy synthetic barcodes
-    # oracle parity on 400 reads drawn from all over the batch
+    # oracle parity on 20 000 reads: 40 blocks of 500 drawn from all over the batch, everything bitwise
     rng = np.random.default_rng(7)
-    idx = np.sort(rng.choice(n, 400, replace=False))
-    off_h, a_s_h, a_e_h = off.cpu().numpy(), a_s.cpu().numpy(), a_e.cpu().numpy()
     po = orc.SegParams(barcode_num_events=K)
-    fpt_g, dist_g, call_g = r1.fpt.cpu().numpy(), r1.dist.cpu().numpy(), r1.call.cpu().numpy()
-    for i in idx:
-        row = sig[int(off_h[i]):int(off_h[i + 1])].cpu().numpy()
-        o = orc.fingerprint_one(row, a_s_h[i], a_e_h[i], po)
-        assert o["status"] == int(r1.status[i])
-        if o["status"] == 0:
-            assert np.array_equal(fpt_g[i], o["fpt"])
-            D = orc.dtw_matrix(o["fpt"][None, :], refs, 15, 0.1)
-            assert np.array_equal(dist_g[i], D[0]) and call_g[i] == int(np.argmin(D[0]))
+    off_h = off.cpu().numpy()
+    checked = 0
+    for lo in np.sort(rng.choice(n - 500, 40, replace=False)):
+        hi = lo + 500
+        o = (off_h[lo:hi + 1] - off_h[lo]).astype(np.int64)
+        s = sig[int(off_h[lo]):int(off_h[hi])].cpu().numpy()
+        fpt, dwell, stats, status = orc.fingerprint_packed(s, o, a_s[lo:hi].cpu().numpy(), a_e[lo:hi].cpu().numpy(), po)
+        assert np.array_equal(status, r1.status[lo:hi].cpu().numpy())
+        okb = status == 0
+        assert np.array_equal(r1.fpt[lo:hi].cpu().numpy()[okb].view(np.uint64), fpt[okb].view(np.uint64))
+        D = orc.dtw_matrix(fpt[okb], refs, 15, 0.1)
+        assert np.array_equal(r1.dist[lo:hi].cpu().numpy()[okb].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(r1.call[lo:hi].cpu().numpy()[okb], orc.argmin_rows(D))
+        checked += int(okb.sum())
+    assert checked > 19_900
+    eng.close()
 
 
 @pytest.mark.gpu
