@@ -368,6 +368,30 @@ def secondary_regimes(device):
         "parity": bool(np.array_equal(fb.status, ostatus) and np.array_equal(fb.fpt[ook], ofpt[ook])
                        and np.array_equal(fb.dwell[ook], odw[ook]) and np.array_equal(Dm.view(np.uint32), oD.view(np.uint32)))}
 
+    # ---- host_workers: the reference's real calling pattern -- P forked workers x 1000-read minibatches sharing this GPU
+    # (file_proc.py:380-454, 1197-1243).  Fresh interpreters (tools/host_workers.py forks before any GPU call); this
+    # process keeps its context but is idle meanwhile.
+    hw = {}
+    for mode, refill, Ps in (("sync", False, (1, 4, 8, 16)), ("pipe", False, (1, 4, 8, 16)), ("pipe", True, (4,))):
+        for P in Ps:
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
+                   "--seconds", "2"] + (["--refill"] if refill else [])
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+                rec = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+            except Exception as e:  # noqa: BLE001
+                rec = {"error": f"{type(e).__name__}: {e}"}
+            hw["%s%s_P%d" % (mode, "_refill" if refill else "", P)] = rec
+    good = [v for v in hw.values() if "reads_per_s" in v]
+    out["host_workers"] = {
+        "workload": "P forked worker processes on ONE GPU, each driving 1000 x 10 000 float32 minibatches (host buffers, PCIe "
+                    "included) through fingerprint + DTW (110-pt x 10 refs) + call; sync = sig_proc.demux_batch on a pageable "
+                    "array, pipe = MinibatchPipeline (page-locked buffers, wdx_demux_submit / wdx_demux_wait); refill = the "
+                    "worker copies a fresh minibatch into the buffer before every call",
+        "host_cpus": effective_cores(), **hw,
+        "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
+        "parity": bool(good) and all(v.get("parity") is True for v in hw.values())}
+
     # ---- live (C5): ticks of 1 / 64 / 512 reads through the live shim, WDX6 shape and the shipped WDX6 shape ------
     live = {}
     for K, nYl in ((K_FPT, 6), (25, 1368)):

@@ -261,6 +261,81 @@ def test_rccl_count_reduction_through_the_c_abi():
     ctx.close()
 
 
+def test_pipelined_minibatches_match_the_synchronous_call_and_the_oracle():
+    """wdx_demux_submit / wdx_demux_wait (two slots, page-locked minibatch buffers) against wdx_demux_batch and the
+    oracle: same bits; error behaviour of the slots."""
+    from warpdemux_amd import pipeline
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K = 110
+    refs = np.random.default_rng(3).normal(size=(10, K))
+    params = sig_proc.SegParams(barcode_num_events=K)
+    pipe = pipeline.MinibatchPipeline(refs, 15, 0.1, params)
+    sig_proc.set_references(refs, 15, 0.1)
+    batches = []
+    for k in range(5):
+        n = [300, 1000, 64, 1, 517][k]
+        mb, a_s, a_e, _ = synth.generate_minibatch(spec, 5000 * k, n, 9000)
+        ok = None
+        if k == 2:
+            ok = np.ones(n, dtype=np.uint8)
+            ok[::7] = 0
+        buf = pipeline.pinned_full((n, 9000), np.nan, np.float32) if k % 2 == 0 else np.empty((n, 9000), np.float32)
+        np.copyto(buf, mb)
+        batches.append((buf, a_s, a_e, ok))
+    outs = list(pipe.run((b[0], b[1], b[2], b[3], True, True) for b in batches))
+    assert len(outs) == len(batches)
+    for (buf, a_s, a_e, ok), got in zip(batches, outs):
+        ref = sig_proc.demux_batch(buf, a_s, a_e, params, success=ok, want_dist=True, want_fpt=True)
+        assert np.array_equal(got.status, ref.status) and np.array_equal(got.call, ref.call)
+        assert np.array_equal(got.dist.view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(got.fpt.view(np.uint64), ref.fpt.view(np.uint64))
+        fpt, dwell, stats, status = orc.fingerprint_batch(buf, a_s, a_e, orc.SegParams(barcode_num_events=K), ok=ok)
+        good = status == 0
+        assert np.array_equal(got.status, status) and np.array_equal(got.fpt[good], fpt[good])
+        D = orc.dtw_matrix(fpt[good], refs, 15, 0.1)
+        assert np.array_equal(got.dist[good].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(got.call[good], orc.argmin_rows(D)) and (got.call[~good] == -1).all()
+    # slots: a busy slot refuses a second minibatch, an idle one has nothing to wait for, outputs must be requested
+    buf, a_s, a_e, ok = batches[0]
+    pipe.submit(0, buf, a_s, a_e, want_dist=False)
+    with pytest.raises(ValueError):
+        pipe.submit(0, buf, a_s, a_e)
+    with pytest.raises(ValueError):
+        pipe.wait(1)
+    r = pipe.wait(0)
+    assert r.dist is None and np.array_equal(r.call, outs[0].call)
+    with pytest.raises(ValueError):
+        pipe.submit(2, buf, a_s, a_e)
+    L = _lib.load()
+    call = np.empty(buf.shape[0], dtype=np.int32)
+    status = np.empty(buf.shape[0], dtype=np.int32)
+    fpt = np.empty((buf.shape[0], K))
+    pipe.submit(1, buf, a_s, a_e, want_fpt=False)
+    with pytest.raises(ValueError):   # fpt was not requested at submit
+        _lib.check(L.wdx_demux_wait(pipe.ctx.handle, 1, _lib.ptr(fpt), None, _lib.ptr(call), _lib.ptr(status)))
+    pipe._held[1] = None
+    # a new reference set while nothing is in flight: picked up by the next submit
+    refs2 = np.random.default_rng(4).normal(size=(10, K))
+    _lib.check(L.wdx_set_refs(pipe.ctx.handle, _lib.ptr(refs2), 10, K, 15, 0.1))
+    pipe.submit(0, buf, a_s, a_e)
+    r2 = pipe.wait(0)
+    good = outs[0].status == 0
+    assert np.array_equal(r2.dist[good].view(np.uint32), orc.dtw_matrix(outs[0].fpt[good], refs2, 15, 0.1).view(np.uint32))
+    pipe.close()
+
+
+@pytest.mark.timeout(600)
+def test_forked_workers_share_the_gpu_through_pipelines():
+    """tools/host_workers.py: 4 forked workers x pipelined 1000-read minibatches on one GPU, oracle-checked."""
+    for mode in ("sync", "pipe"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", "4", "--mode", mode,
+                            "--seconds", "1", "--refill"], capture_output=True, text=True, timeout=500, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rec["parity"] and rec["workers"] == 4 and rec["reads_per_s"] > 0
+
+
 def test_long_adapter_windows_through_live_ticks_and_device_entry_points():
     """Windows of 11 201 .. 15 200 samples (legal in the reference's RNA002 config, the chemistry the live path
     serves: live_balancing/worker.py:36-44) through wdx_live_tick, wdx_fingerprint_dev and wdx_demux_dev."""

@@ -57,6 +57,12 @@ struct wdx_ctx {
     wdx::SvmDev svm{};
     bool svm_set = false;
     wdx::Comm *comm = nullptr;
+    // pipelined minibatches (wdx_demux_submit / wdx_demux_wait): two child contexts, each with its own stream and
+    // workspaces, sharing this context's resident reference set; the fields below describe a child's batch in flight
+    wdx_ctx *slots[2] = {nullptr, nullptr};
+    bool slot_busy = false, slot_has_fpt = false, slot_has_dist = false;
+    int64_t slot_n = 0, slot_K = 0, slot_nY = 0;
+    size_t slot_off[4] = {0, 0, 0, 0};
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[wdx::kNumTimed];
