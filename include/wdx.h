@@ -112,6 +112,7 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_FAST_EXACT_SCORES 7 /* fast fingerprint kernel: exact t-scores, no approximate keys       */
 #define WDX_OPT_FAST_MAIN_CAP 8     /* main fast instantiation: 5120 or 6144 samples (0 = chosen by batch)  */
 #define WDX_OPT_FAST_CHAIN_MIN_READS 9 /* smallest batch that takes the approximate-keys launch chain (0 = 2048) */
+#define WDX_OPT_EXACT_NO_PEAK_LIST 10  /* exact kernel: suppression / top-E over positions, never over the peak list */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

@@ -1013,8 +1013,8 @@ def test_fingerprint_randomised_configs_and_signal_styles(seed):
         a_s[i], a_e[i] = st, st + ln
     ok = (rng.uniform(size=n) > 0.04).astype(np.uint8)
     kw = dict(padding=int(rng.choice([0, 30, 100])), outlier_thresh=float(rng.choice([3.0, 5.0, 8.0])),
-              num_events=int(rng.choice([60, 110, 120])), min_obs_per_base=int(rng.choice([2, 3, 6, 9])),
-              running_stat_width=int(rng.choice([12, 12, 12, 10, 18])),
+              num_events=int(rng.choice([60, 110, 120])), min_obs_per_base=int(rng.choice([2, 3, 6, 9, 15])),
+              running_stat_width=int(rng.choice([12, 12, 12, 10, 18, 30])),
               seg_norm=str(rng.choice(["mean", "median", "none"])))
     kw["barcode_num_events"] = int(rng.choice([10, 25, kw["num_events"]]))
     ph, po = sig_proc.SegParams(**kw), orc.SegParams(**kw)
@@ -1026,6 +1026,17 @@ def test_fingerprint_randomised_configs_and_signal_styles(seed):
         ch = sig_proc.fingerprint_batch(mb, a_s, a_e, ph, success=ok)
     assert np.array_equal(ch.status, status), (kw, np.flatnonzero(ch.status != status))
     assert _same(ch.fpt, fpt) and _same(ch.dwell, dwell) and _same(ch.stats, stats), kw
+    # the exact general kernel alone, with its suppression / top-E on the compact peak list and in position space
+    for no_list in (0, 1):
+        ctx = _lib.default_context(None)
+        ctx.set_option(_lib.OPT_EXACT_NO_PEAK_LIST, no_list)
+        try:
+            with _exact_path():
+                ex = sig_proc.fingerprint_batch(mb, a_s, a_e, ph, success=ok)
+        finally:
+            ctx.set_option(_lib.OPT_EXACT_NO_PEAK_LIST, 0)
+        assert np.array_equal(ex.status, status), (kw, no_list, np.flatnonzero(ex.status != status))
+        assert _same(ex.fpt, fpt) and _same(ex.dwell, dwell) and _same(ex.stats, stats), (kw, no_list)
     # (some parameter draws fail every read in the reference too -- statuses are compared above; the draws
     # as a whole must exercise the success path)
     _RANDOMISED_OK.append(int((status == 0).sum()))

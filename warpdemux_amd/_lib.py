@@ -30,6 +30,7 @@ OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBU
 OPT_FAST_EXACT_SCORES = 7
 OPT_FAST_MAIN_CAP = 8
 OPT_FAST_CHAIN_MIN_READS = 9
+OPT_EXACT_NO_PEAK_LIST = 10
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 

@@ -409,6 +409,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_FAST_EXACT_SCORES: ctx->knobs.fast_exact_scores = value != 0; break;
         case WDX_OPT_FAST_MAIN_CAP: ctx->knobs.fast_main_cap = (int)value; break;
         case WDX_OPT_FAST_CHAIN_MIN_READS: ctx->knobs.fast_chain_min = (int)value; break;
+        case WDX_OPT_EXACT_NO_PEAK_LIST: ctx->knobs.exact_no_list = value != 0; break;
         default:
             set_error("unknown option %d", (int)option);
             return WDX_ERR_INVALID;

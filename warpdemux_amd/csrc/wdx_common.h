@@ -32,6 +32,7 @@ struct Knobs {
     int fast_chain_min = 0;     // WDX_OPT_FAST_CHAIN_MIN_READS: batch size from which the launch chain is used (0 = 2048)
     int fast_main_cap = 0;      // WDX_OPT_FAST_MAIN_CAP: 5120 / 6144 forces the main fast instantiation (0 = by batch)
     bool fast_exact_scores = false;  // WDX_OPT_FAST_EXACT_SCORES: fast fingerprint kernel without the approximate first attempt
+    bool exact_no_list = false;      // WDX_OPT_EXACT_NO_PEAK_LIST: exact kernel's suppression / top-E in position space only
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): a launch on the live

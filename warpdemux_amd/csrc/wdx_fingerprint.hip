@@ -78,6 +78,7 @@ struct FpArgs {
     RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
     double *big_scores;  // kBigSlots x kBigCap doubles: score curves of windows beyond the LDS capacity (nullable)
     int defer_big;       // 1: a window beyond `cap` is left to fingerprint_big_kernel (no status written here)
+    int no_list;         // WDX_OPT_EXACT_NO_PEAK_LIST: fp_segment in position space only (diagnostic)
 };
 
 struct alignas(8) FpShared {
@@ -470,10 +471,33 @@ __device__ void block_small_median(const double *a, int n, FpShared &sh, int slo
 // -> event means over sig (sig_proc.py:176-198, segmentation.py:48-74).  Used for the adapter and, in the
 // consensus-refinement branch, once more for the barcode tail of the same score curve.  All threads call;
 // returns a block-uniform WDX_READ_* status; on success cpts[0..nseg] and ev[0..nseg).
+// block-wide exclusive scan of one int per thread (chunk counts); total = block sum.  Two barriers.
+template <int BLOCK>
+__device__ __forceinline__ int block_excl_scan(int v, FpShared &sh, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();  // sh.red_a may still be read by the previous user
+    if (lane == 63) sh.red_a[wave] = (unsigned)incl;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < BLOCK / 64; ++k) {
+        const int w = (int)sh.red_a[k];
+        base += k < wave ? w : 0;
+        total += w;
+    }
+    return base + incl - v;
+}
+
 template <int BLOCK>
 __device__ int fp_segment(const double *scores, unsigned char *state, const int ns, const int d_eff, const int W,
                           const int E, const bool accept_less, const float *sig, const int n_end, int *cpts, double *ev,
-                          unsigned *hist, FpShared &sh, int &nseg, int &nms_iters) {
+                          unsigned *hist, FpShared &sh, int &nseg, int &nms_iters, const bool no_list = false) {
     const int tid = threadIdx.x;
     // ---- P3: find_peaks(scores, distance=d_eff) ----------------------------------
     for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
@@ -487,6 +511,145 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
         }
     }
     __syncthreads();
+    // The local maxima (about ns / 5.6 of the positions) are compacted into a position-ordered LIST that overwrites
+    // the state bytes in place -- uint16 positions, then one state byte per peak: 3 bytes per peak against one byte per
+    // position, so it fits whenever np <= ns / 3 (else, and with WDX_OPT_EXACT_NO_PEAK_LIST, the position-space
+    // code below runs; same decisions, same results).  Suppression, the top-E cut and the boundaries then walk
+    // ~ns / 5.6 entries instead of ns positions: the suppression's neighbourhood scan is a few list entries instead
+    // of 2 (d - 1) state bytes, and every pass of the select is 5.6x shorter.
+    int nsel;
+    bool use_list;
+    int np = 0, lbase = 0;
+    unsigned lbits = 0;
+    const int lchunk = (ns + BLOCK - 1) / BLOCK;  // <= 32: cap <= 16 384, BLOCK >= 512
+    const int lc0 = tid * lchunk;
+    {
+        const int lc1 = min(ns, lc0 + lchunk);
+        for (int i = lc0; i < lc1; ++i) lbits |= (state[i] == ST_UNDECIDED ? 1u : 0u) << (i - lc0);
+        lbase = block_excl_scan<BLOCK>(__popc(lbits), sh, np);  // (its barriers: every state byte has been read)
+        use_list = !no_list && lchunk <= 32 && 3 * np + 8 <= ns;
+    }
+    if (use_list) {
+        unsigned short *lpos = reinterpret_cast<unsigned short *>(state);
+        unsigned char *lst = state + ((2 * np + 3) & ~3);
+        {
+            int o = lbase;
+            unsigned b = lbits;
+            while (b) {
+                const int j = __ffs((int)b) - 1;
+                b &= b - 1;
+                lpos[o] = (unsigned short)(lc0 + j);
+                lst[o] = ST_UNDECIDED;
+                ++o;
+            }
+        }
+        __syncthreads();
+        // greedy suppression by priority (see the position-space form below for the rule): a peak's rivals are the list
+        // neighbours closer than d_eff; ties -> the LATER peak outranks
+        for (;;) {
+            int pending = 0;
+            for (int k = tid; k < np; k += BLOCK) {
+                if (lst[k] != ST_UNDECIDED) continue;
+                const int p = lpos[k];
+                const double s = scores[p];
+                bool kept_near = false, wait = false;
+                for (int q = k - 1; q >= 0 && p - (int)lpos[q] < d_eff; --q) {
+                    const unsigned char st = lst[q];
+                    if (st == ST_KEPT) kept_near = true;
+                    else if (st == ST_UNDECIDED && scores[lpos[q]] > s) wait = true;
+                }
+                for (int q = k + 1; q < np && (int)lpos[q] - p < d_eff; ++q) {
+                    const unsigned char st = lst[q];
+                    if (st == ST_KEPT) kept_near = true;
+                    else if (st == ST_UNDECIDED) {
+                        const double sq = scores[lpos[q]];
+                        if (sq > s || sq == s) wait = true;
+                    }
+                }
+                if (kept_near) lst[k] = ST_DROPPED;
+                else if (!wait) lst[k] = ST_KEPT;
+                else pending = 1;
+            }
+            ++nms_iters;
+            if (!__syncthreads_or(pending)) break;
+        }
+        // ---- P4 on the list: keep the E highest peaks (sig_proc.py:185-188) --------------------------
+        unsigned long long kmin = ~0ull, kmax = 0;
+        unsigned cnt = 0;
+        for (int k = tid; k < np; k += BLOCK) {
+            if (lst[k] == ST_KEPT) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(scores[lpos[k]]);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+                cnt++;
+            }
+        }
+        unsigned long long gmin, gmax;
+        unsigned nk;
+        block_minmax64_count<BLOCK>(kmin, kmax, cnt, sh, gmin, gmax, nk);
+        if ((int)nk < E && !accept_less) return WDX_READ_FAIL_SEGMENT;
+        if (nk == 0) return WDX_READ_FAIL_UNKNOWN;  // valid_cpts[0] on an empty array
+        if ((int)nk <= E) {
+            nsel = (int)nk;
+            __syncthreads();
+            for (int k = tid; k < np; k += BLOCK)
+                if (lst[k] == ST_KEPT) lst[k] = ST_SELECTED;
+        } else {
+            nsel = E;
+            auto keyfn = [&](int k, unsigned long long &key) {
+                key = (unsigned long long)__double_as_longlong(scores[lpos[k]]);
+                return lst[k] == ST_KEPT;
+            };
+            const unsigned long long T = block_select_u64<BLOCK>(keyfn, np, nk - (unsigned)E, gmin, gmax, hist, sh);
+            unsigned gt = 0, eq = 0, z0 = 0xffffffffu;
+            for (int k = tid; k < np; k += BLOCK) {
+                if (lst[k] == ST_KEPT) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(scores[lpos[k]]);
+                    gt += key > T;
+                    eq += key == T;
+                }
+            }
+            unsigned ggt, geq, dmy;
+            block_minmax_count<BLOCK>(z0, gt, eq, sh, dmy, dmy, geq);  // geq = sum(eq)
+            block_minmax_count<BLOCK>(z0, 0u, gt, sh, dmy, dmy, ggt);  // ggt = sum(gt)
+            const unsigned need = (unsigned)E - ggt;  // 1 <= need <= geq
+            __syncthreads();
+            for (int k = tid; k < np; k += BLOCK) {
+                if (lst[k] == ST_KEPT) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(scores[lpos[k]]);
+                    if (key > T || (key == T && need == geq)) lst[k] = ST_SELECTED;
+                }
+            }
+            __syncthreads();
+            if (need != geq && tid == 0) {
+                // exact score ties at the cut: the stable order keeps the LAST `need` of them
+                unsigned left = need;
+                for (int k = np - 1; k >= 0 && left; --k) {
+                    if (lst[k] == ST_KEPT && (unsigned long long)__double_as_longlong(scores[lpos[k]]) == T) {
+                        lst[k] = ST_SELECTED;
+                        --left;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P5 on the list: boundaries 0, peaks+W (ascending), n  (sig_proc.py:188-196) ---------------
+        {
+            const int c2 = (np + BLOCK - 1) / BLOCK;
+            const int k0 = tid * c2, k1 = min(np, k0 + c2);
+            int local = 0;
+            for (int k = k0; k < k1; ++k) local += lst[k] == ST_SELECTED;
+            int tot;
+            int o = block_excl_scan<BLOCK>(local, sh, tot);
+            for (int k = k0; k < k1; ++k)
+                if (lst[k] == ST_SELECTED) cpts[1 + o++] = (int)lpos[k] + W;
+            if (tid == 0) {
+                cpts[0] = 0;
+                cpts[nsel + 1] = n_end;
+            }
+            __syncthreads();
+        }
+    } else {
     {
         // greedy suppression by priority == fixed point of: a peak is KEPT once every higher-priority
         // peak closer than d_eff is DROPPED, and DROPPED as soon as one of them is KEPT.
@@ -518,7 +681,6 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
     }
 
     // ---- P4: keep the E highest peaks (sig_proc.py:185-188) -----------------------------------------
-    int nsel;
     {
         unsigned long long kmin = ~0ull, kmax = 0;
         unsigned cnt = 0;
@@ -608,6 +770,7 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
             cpts[nsel + 1] = n_end;
         }
         __syncthreads();
+    }
     }
     nseg = nsel + 1;
 
@@ -787,12 +950,12 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *s
         if (n_end2 != n - sbs) {
             // still "event segmentation failed" when the tail has too few peaks (that return comes first)
             const int st0 = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2,
-                                              false, sig + sbs, min(n_end2, n - sbs), cpts, zz, hist, sh, nseg2, it2);
+                                              false, sig + sbs, min(n_end2, n - sbs), cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
             finish(st0 == WDX_READ_FAIL_SEGMENT ? WDX_READ_FAIL_SEGMENT : WDX_READ_FAIL_UNKNOWN, false);
             return;
         }
         const int st = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2, false,
-                                         sig + sbs, n_end2, cpts, zz, hist, sh, nseg2, it2);
+                                         sig + sbs, n_end2, cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
         if (st != WDX_READ_OK) {
             finish(st, false);
             return;
@@ -1040,7 +1203,7 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     int nms_iters = 0, nseg = 0;
     {
         const int st = fp_segment<BLOCK>(scores, state, ns, d_eff, W, E, P.accept_less_cpts != 0, sig, n, cpts, ev,
-                                         hist, sh, nseg, nms_iters);
+                                         hist, sh, nseg, nms_iters, A.no_list != 0);
         if (st != WDX_READ_OK) {
             finish(st);
             return;
@@ -1092,16 +1255,18 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
         }
         __syncthreads();
 
-        // stats (sig_proc.py:562-567)
-        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = (double)(cpts[s + 1] - cpts[s]);
-        block_small_median<BLOCK>(tmp, nseg, sh, 0);
-        const double dt_med = sh.stat[0];
-        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(tmp[s] - dt_med);
-        block_small_median<BLOCK>(tmp, nseg, sh, 1);
-        block_small_median<BLOCK>(ev, nseg, sh, 4);
-        const double ev_med = sh.stat[4];
-        for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(ev[s] - ev_med);
-        block_small_median<BLOCK>(tmp, nseg, sh, 5);
+        // stats (sig_proc.py:562-567) -- only when the caller takes them (four medians by rank counting)
+        if (A.stats) {
+            for (int s = tid; s < nseg; s += BLOCK) tmp[s] = (double)(cpts[s + 1] - cpts[s]);
+            block_small_median<BLOCK>(tmp, nseg, sh, 0);
+            const double dt_med = sh.stat[0];
+            for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(tmp[s] - dt_med);
+            block_small_median<BLOCK>(tmp, nseg, sh, 1);
+            block_small_median<BLOCK>(ev, nseg, sh, 4);
+            const double ev_med = sh.stat[4];
+            for (int s = tid; s < nseg; s += BLOCK) tmp[s] = fabs(ev[s] - ev_med);
+            block_small_median<BLOCK>(tmp, nseg, sh, 5);
+        }
 
         if (nseg < K) {
             finish(WDX_READ_FAIL_UNKNOWN);  // np.pad(int64 dwell, NaN) raises in the reference
@@ -1309,7 +1474,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     const bool with_huge = max_len > kExactLdsCap && d_big != nullptr && !d_prof;
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
              p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, 1, RefineDev{},
-             d_big, with_huge ? 1 : 0};
+             d_big, with_huge ? 1 : 0, knobs.exact_no_list ? 1 : 0};
     if (rf) {
         if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
             set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,
@@ -1333,10 +1498,14 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                                       : launch_fp_chunks<1024, true>(A, lds, stream, n_launches);
 
     // fast path for the common case + exact slow path for whatever it declines
+    // (the fast kernels take reads whose EFFECTIVE parameters are window width 12 and distance <= 9; with a configured
+    // width other than 12 or a configured distance beyond 9 only a few very short reads would qualify -- sig_proc.py:
+    // 526-533 shrinks the parameters for those -- and a launch chain whose main kernel declines nearly every read
+    // costs more than it saves: 1.62 against 1.99 M reads/s on the RNA002 triple (110, 15, 30))
     const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
-                         p.running_stat_width >= kFW && p.min_obs_per_base >= 1 && cap >= 512 &&
-                         !knobs.exact_path && !rf;
+                         p.running_stat_width == kFW && p.min_obs_per_base >= 1 && p.min_obs_per_base <= 2 * kNB + 1 &&
+                         cap >= 512 && !knobs.exact_path && !rf;
     if (fast_ok) {
         // A chain of launches, each handing what it cannot take to the next through device-side lists:
         //   main    one workgroup per read; the instantiation follows the longest adapter window of the batch:
