@@ -68,3 +68,29 @@ def test_subseq_match_properties():
     # shifting both by a constant changes nothing; scaling the penalty to zero never lengthens the distance
     s = np.concatenate([rng.normal(size=12), q + 0.05 * rng.normal(size=q.size), rng.normal(size=12)])
     assert orc.subseq_match(q, s) == orc.subseq_match(q + 2.5, s + 2.5)
+
+
+def test_subseq_match_hand_derived_cases():
+    """Small cases worked out by hand from dtaidistance's published algorithm (warping_paths with penalty^2 on the
+    two non-diagonal steps and psi relaxations, SubsequenceAlignment.best_match = argmin of the last row / len(query),
+    best_path walking back over the sqrt'ed matrix with np.argmin([diag, up, left]) -- first minimum wins), as
+    sig_proc.py:287-306 calls it.  D below is the squared accumulated cost, rows = query, columns = series (1-based).
+
+    1. psi at the series' beginning.  q = [1,2,3], s = [9,9,1,2,3], penalty 0.  With psi_series_begin = 1 only
+       D(0,0) = D(0,1) = 0: row 1 = [64,64,64,65,69], row 2 = [113,113,65,64,65], row 3 = [149,149,69,65,64]
+       -> end index 4; back-trace (3,5) diag (2,4) diag (1,3) left (1,2) diag (0,1): first series column 2
+       -> start index 1.  With psi_series_begin >= 2 the copy is matched for free: (2, 4).
+    2. tie-break.  q = [0,1], s = [0,0.3,1], penalty 0, series fully relaxed: row 1 = [0,0.09,1], row 2 =
+       [1,0.49,0.09] -> end index 2; (2,3) diag (1,2), whose three predecessors D(0,1) = D(0,2) = D(1,1) = 0 tie:
+       argmin takes the diagonal -> start index 1 (a walk preferring `left` would reach start index 0).
+    3. penalty is SQUARED.  q = [0,1,1], s = [5,0,1,5], series fully relaxed.  penalty 0: last row [57,2,0,16]
+       -> end 2, path (3,3) up (2,3) diag (1,2) diag -> (1, 2).  penalty 5 (25 per non-diagonal step): rows
+       [25,0,1,25], [66,26,0,17], [107,52,25,16] -> end 3, three diagonal steps -> (1, 3); an un-squared penalty
+       (5 per step) would leave the vertical step at cost 5 < 16 and return (1, 2)."""
+    assert orc.subseq_match([1, 2, 3], [9, 9, 1, 2, 3], penalty=0.0, psi=(0, 0, 1, 0)) == (1, 4)
+    assert orc.subseq_match([1, 2, 3], [9, 9, 1, 2, 3], penalty=0.0, psi=(0, 0, 2, 0)) == (2, 4)
+    assert orc.subseq_match([1, 2, 3], [9, 9, 1, 2, 3], penalty=0.0, psi=(0, 0, 5, 0)) == (2, 4)
+    assert orc.subseq_match([0, 1], [0, 0.3, 1], penalty=0.0, psi=(0, 0, 3, 0)) == (1, 2)
+    assert orc.subseq_match([0, 1, 1], [5, 0, 1, 5], penalty=0.0, psi=(0, 0, 4, 0)) == (1, 2)
+    assert orc.subseq_match([0, 1, 1], [5, 0, 1, 5], penalty=5.0, psi=(0, 0, 4, 0)) == (1, 3)
+    assert orc.subseq_match([0, 1, 1], [5, 0, 1, 5], penalty=np.sqrt(5.0), psi=(0, 0, 4, 0)) == (1, 2)   # 5 per step: the un-squared reading
