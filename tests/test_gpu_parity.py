@@ -396,6 +396,32 @@ def test_long_window_golden_vectors(golden_dir):
             assert fb.status[i] == 0 and _same(fb.fpt[i], g[f"fpt_{k}"]) and _same(fb.dwell[i], g[f"dwell_{k}"])
 
 
+@pytest.mark.parametrize("triple", [(110, 15, 30), (120, 9, 18), (110, 9, 30), (60, 17, 30), (110, 2, 18)])
+def test_fast_kernels_of_the_other_shipped_triples(triple):
+    """The fast kernels' instantiations for window widths 18 and 30 (tRNA and RNA002 triples; suppression reach up
+    to d = 17): synthetic RNA004-like reads, ADC-quantised reads (ties, plateaus -> exact-score tiles, retries) and
+    short reads whose parameters shrink (sig_proc.py:526-533), through the launch chain (approximate keys) and
+    through the small-batch form (exact scores), against the oracle."""
+    E, d, w = triple
+    spec = synth.SynthSpec(n_barcodes=10)
+    n = 2600
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 777, n, 9000)
+    rng = np.random.default_rng(E * d + w)
+    q = slice(2000, 2300)                                   # quantised block
+    mb[q] = np.round(mb[q] / 0.1755) * np.float32(0.1755)
+    for i in range(2300, 2400):                              # short windows: effective width / distance shrink
+        a_e[i] = a_s[i] + int(rng.integers(300, 3300))
+    kw = dict(num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+    assert (status == 0).sum() > 0.9 * n
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))               # n >= 2048: launch chain
+    assert np.array_equal(fb.status, status)
+    good = status == 0
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good])
+    sm = sig_proc.fingerprint_batch(mb[:700], a_s[:700], a_e[:700], sig_proc.SegParams(**kw))   # exact scores from the start
+    assert np.array_equal(sm.status, status[:700]) and _same(sm.fpt[good[:700]], fpt[:700][good[:700]])
+
+
 @pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18)])
 def test_long_windows_in_large_batches_vs_oracle(triple):
     """3 000 reads whose windows straddle every capacity edge (5 120 / 6 144 / 8 192 / 11 200 / 16 384) through the

@@ -1436,6 +1436,19 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
 // four counters + four read lists (slow, big0, big1, retry: see launch_fingerprint)
 int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 16 * (n_reads > 0 ? n_reads : 0); }
 
+// The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
+//   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
+//   2: W = 18, d <= 9  (tRNA triple: 120, 9, 18; the tRNA config itself also refines -> exact kernel)
+//   3: W = 30, d <= 17 (RNA002 triple: 110, 15, 30)
+// 2 and 3 run the 6144-sample instantiation as main kernel and the 8192-sample one for longer windows and retries.
+static int fast_combo(const wdx_seg_params &p) {
+    if (p.min_obs_per_base < 1) return 0;
+    if (p.running_stat_width == 12 && p.min_obs_per_base <= 9) return 1;
+    if (p.running_stat_width == 18 && p.min_obs_per_base <= 9) return 2;
+    if (p.running_stat_width == 30 && p.min_obs_per_base <= 17) return 3;
+    return 0;
+}
+
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
                        const int32_t *d_a_end, const uint8_t *d_ok, const wdx_seg_params &p,
@@ -1504,8 +1517,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     // costs more than it saves: 1.62 against 1.99 M reads/s on the RNA002 triple (110, 15, 30))
     const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
-                         p.running_stat_width == kFW && p.min_obs_per_base >= 1 && p.min_obs_per_base <= 2 * kNB + 1 &&
-                         cap >= 512 && !knobs.exact_path && !rf;
+                         fast_combo(p) != 0 && (fast_combo(p) == 1 || !d_prof) && cap >= 512 && !knobs.exact_path && !rf;
     if (fast_ok) {
         // A chain of launches, each handing what it cannot take to the next through device-side lists:
         //   main    one workgroup per read; the instantiation follows the longest adapter window of the batch:
@@ -1524,13 +1536,16 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const int64_t chain_min = knobs.fast_chain_min > 0 ? knobs.fast_chain_min : 2048;
         const bool large_batch = n_reads >= chain_min;
         const bool approx = large_batch && !knobs.fast_exact_scores;
+        const int combo = fast_combo(p);
+        const int nbt = combo == 3 ? 2 : 1;
         int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
         if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
+        if (combo != 1) capF = 6144;  // the other triples: one main instantiation
         // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
         // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
-        const size_t flds = fast_lds_bytes(capF, capP);
+        const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
         int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads;
@@ -1549,8 +1564,20 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             F.big_list = big1;
         }
         void (*kern)(FastArgs) = nullptr;
+        void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
+        void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
         int slot = 0;
-        if (capF == 4096) {
+        if (combo == 2) {
+            kern = fingerprint_fast_kernel<kNptLarge, false, 18, 1>;
+            kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 18, 1>;
+            kern_ls = fingerprint_fast_list_kernel<kNptHuge, 18, 1>;
+            slot = 2;
+        } else if (combo == 3) {
+            kern = fingerprint_fast_kernel<kNptLarge, false, 30, 2>;
+            kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 30, 2>;
+            kern_ls = fingerprint_fast_list_kernel<kNptHuge, 30, 2>;
+            slot = 2;
+        } else if (capF == 4096) {
             kern = d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>;
         } else if (capF == 5120) {
             kern = d_prof ? fingerprint_fast_kernel<kNptMid, true> : fingerprint_fast_kernel<kNptMid, false>;
@@ -1559,8 +1586,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             kern = d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>;
             slot = 2;
         }
-        static LdsAttr attr_fast[6];
-        if (int rc = attr_fast[(d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
+        static LdsAttr attr_fast[3][6];
+        if (int rc = attr_fast[combo - 1][(d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
@@ -1588,29 +1615,29 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // the list kernels
         const int64_t grid = n_reads < 1024 ? n_reads : 1024;  // striding kernels: every CU busy, nothing more
         const int capF1 = 6144, capP1 = 1376, capF2 = 8192, capP2 = 1856;
-        const size_t flds1 = fast_lds_bytes(capF1, capP1), flds2 = fast_lds_bytes(capF2, capP2);
-        static LdsAttr attr_l1, attr_huge;
+        const size_t flds1 = fast_lds_bytes(capF1, capP1, nbt), flds2 = fast_lds_bytes(capF2, capP2, nbt);
+        static LdsAttr attr_l1[3], attr_huge[3];
         if (with_big0 || (approx && chain))
-            if (int rc = attr_l1.ensure(fingerprint_fast_list1_kernel<kNptLarge>, flds1)) return rc;
+            if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
         if (with_big0 || with_big1 || (approx && chain))
-            if (int rc = attr_huge.ensure(fingerprint_fast_list_kernel<kNptHuge>, flds2)) return rc;
+            if (int rc = attr_huge[combo - 1].ensure(kern_ls, flds2)) return rc;
         if (with_big0) {
             // 11 % of RNA004 adapter windows are longer than 5120 samples: a grid for a quarter of the batch, one
             // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
             const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
             FastArgs F1{A, capF1, capP1, count, list, with_big1 ? count + 2 : nullptr, with_big1 ? big1 : nullptr,
                         count + 1, big0, 0u, F.retry_count, F.retry_list};
-            launch_sliced(fingerprint_fast_list1_kernel<kNptLarge>, F1, g1, flds1, false);
+            launch_sliced(kern_l1, F1, g1, flds1, false);
             if (g1 < n_reads) {
                 FastArgs F1b{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big0, (unsigned)g1, F.retry_count,
                              F.retry_list};
-                hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2,
+                hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
                                    stream, F1b);
             }
         }
         if (with_big1) {
             FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list};
-            hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2, stream,
+            hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2, stream,
                                F2);
         }
         if (approx && chain) {
@@ -1619,11 +1646,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int64_t g3 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 64));
             FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr};
             F3.a.exact_scores = 1;
-            launch_sliced(fingerprint_fast_list1_kernel<kNptLarge>, F3, g3, flds1, false);
+            launch_sliced(kern_l1, F3, g3, flds1, false);
             if (g3 < n_reads) {
                 FastArgs F3b{F3.a, capF2, capP2, count, list, nullptr, nullptr, count + 3, retry, (unsigned)g3, nullptr,
                              nullptr};
-                hipLaunchKernelGGL((fingerprint_fast_list_kernel<kNptHuge>), dim3((unsigned)grid), dim3(FB), flds2,
+                hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
                                    stream, F3b);
             }
         }
