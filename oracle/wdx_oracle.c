@@ -8,11 +8,22 @@
  *   stage A (fingerprint chain, A0-A6): PINNED -- checked bit-for-bit against outputs of the
  *     reference's own warpdemux.sig_proc / _c_segmentation imported in the build container
  *     (tests/golden/make_golden.py -> tests/golden/ fixtures; NumPy 2.2.6 / SciPy 1.15.3).
- *   stage B (banded DTW): PARITY UNPINNED -- the arithmetic lives in dtaidistance==2.3.13
- *     (environment.yml:13), which is neither vendored in the reference tree nor installable
- *     here.  This file restates the published dtw_distance recurrence and is
- *     anchored on the library's documented example, a literal full-matrix restatement and a
- *     property suite (tests/test_oracle_dtw.py).
+ *   stage B (banded DTW): PINNED TO REFERENCE-HELD DATA -- the arithmetic lives in
+ *     dtaidistance==2.3.13 (environment.yml:13), which is neither vendored in the reference tree
+ *     nor installable here, and the reference has no tests at this seam; but its five shipped
+ *     DTW_SVM models were trained by libsvm on exp(-D) of the genuine library's distance matrix,
+ *     and the optimality (KKT) conditions that training left behind hold under this file's
+ *     distances to libsvm's own tolerance (5.6e-4 < eps = 1e-3 over ~23 000 free support vectors)
+ *     and are violated >= 17x by every single change to the recurrence (penalty not squared,
+ *     band edge +-1, no sqrt, ...): tests/test_oracle_dtw_kkt.py, fixture g9
+ *     (tests/golden/make_golden_kkt.py).  Resolution: systematic deviations above ~2e-4
+ *     relative; rounding-level agreement is not claimed.  Also anchored on the library's
+ *     documented examples, a literal full-matrix restatement and a property suite
+ *     (tests/test_oracle_dtw.py).
+ *   subsequence match of the consensus refinement (dtaidistance warping_paths_fast +
+ *     SubsequenceAlignment.best_match): PARITY UNPINNED -- no reference-held artefact encodes
+ *     its output; restated from the published algorithm, cross-checked against an independent
+ *     pure-Python restatement (fixture g8) and hand-derived cases (tests/test_oracle_refine.py).
  *
  * Every function cites the reference lines it follows (paths relative to /root/reference).
  * All double arithmetic must be compiled WITHOUT fused-multiply-add contraction
@@ -955,7 +966,7 @@ int wdx_oracle_fingerprint_packed(const float *sig, const int64_t *off, int64_t 
 
 /* ------------------------------------------------------------------------------------------ */
 /* B1: banded DTW, dtaidistance 2.3.x dtw_distance semantics (call sites     */
-/*     parallel_distances.py:34-43, 59-67).  PARITY UNPINNED, see header.                      */
+/*     parallel_distances.py:34-43, 59-67).  Pinned by the shipped models' KKT conditions.    */
 /* ------------------------------------------------------------------------------------------ */
 
 /* distance between s1[l1] and s2[l2]; window<=0 -> unbanded; penalty is squared internally.

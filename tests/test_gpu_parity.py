@@ -616,7 +616,8 @@ def test_fast_score_sequences_match_the_compilers_sqrt_and_division():
 
 
 def test_dtaidistance_cross_check_if_available():
-    """the DTW seam is parity-unpinned because dtaidistance is not in the reference tree.  If the
+    """dtaidistance is not in the reference tree (the DTW seam is pinned through the shipped models'
+    KKT conditions instead, tests/test_gpu_kkt.py).  If the
     box this runs on happens to have the library, compare the genuine call of parallel_distances.py:59-67 with the
     engine on >= 1e4 pairs of both shapes; otherwise skip (never fail for its absence)."""
     dtai = pytest.importorskip("dtaidistance")

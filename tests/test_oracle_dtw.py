@@ -1,7 +1,7 @@
-"""Anchors for the DTW half of the oracle.  PARITY UNPINNED: dtaidistance 2.3.13 is not in the
-reference tree nor installable here, so these check the restated recurrence
-against the library's documented example, a literal full-matrix form, exhaustive path enumeration
-and invariants."""
+"""Anchors for the DTW half of the oracle: the restated recurrence against the library's
+documented example, a literal full-matrix form, exhaustive path enumeration and invariants.  dtaidistance 2.3.13 is
+not in the reference tree nor installable here; the pin to reference-held data is tests/test_oracle_dtw_kkt.py (the
+KKT conditions of the five shipped DTW_SVM models)."""
 import itertools
 import math
 
