@@ -163,3 +163,53 @@ def test_refinement_randomised_parameters_vs_oracle(seed):
     good, rep = status == 0, (status == 0) | (status == 6)
     assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]), seed
     assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep]), seed
+
+
+def test_refinement_behind_the_fast_kernels_matches_the_exact_kernel_and_the_oracle(golden_dir):
+    """The tRNA flow at batch size: a fast kernel segments the adapter, fingerprint_refine_tail_kernel does the rest
+    (statistics, subsequence match, the barcode's segmentation from the re-clipped tail).  Reads with a barcode tail
+    beyond the tail kernel's capacity, NaN windows and failed detections travel on to the exact kernel.  Everything
+    against the exact kernel alone (WDX_OPT_EXACT_PATH) and against the oracle, bit for bit."""
+    from warpdemux_amd import _lib
+
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]
+    rng = np.random.default_rng(77)
+    n = 700
+    rows = []
+    for i in range(n):
+        n_lead = int(rng.integers(2, 34))
+        n_tail = 30 if i % 9 else int(rng.integers(70, 110))          # every ninth read: a tail of > 2048 samples
+        emb = rng.random() > 0.1
+        lv = list(rng.normal(0, 1, n_lead)) + list(consensus if emb else rng.normal(0, 1, consensus.size)) + list(rng.normal(0, 1, n_tail))
+        lv = np.array(lv) * 12.0 + 85.0
+        dw = rng.integers(12, 50, lv.size)
+        rows.append((np.repeat(lv, dw) + rng.normal(0, rng.uniform(0.8, 2.5), int(dw.sum()))).astype(np.float32)[:8100])
+    stride = max(r.size for r in rows)
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, : r.size] = r
+    a_s = np.full(n, 100, dtype=np.int32)
+    a_e = np.array([r.size - 100 for r in rows], dtype=np.int32)
+    ok = np.ones(n, dtype=np.uint8)
+    ok[3] = 0
+    mb[5, 1500:1503] = np.nan
+    seg = dict(min_obs_per_base=9, running_stat_width=18, num_events=120)
+    ref = dict(barcode_segm_events=25, barcode_keep_events=25)
+    hp, hr = sig_proc.SegParams(barcode_num_events=25, **seg), sig_proc.RefineParams(query=consensus, **ref)
+    fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, hp, hr, success=ok)
+    ctx = _lib.default_context(None)
+    ctx.set_option(_lib.OPT_EXACT_PATH, 1)
+    try:
+        ex = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, hp, hr, success=ok)
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_PATH, 0)
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(
+        mb, a_s, a_e, orc.SegParams(barcode_num_events=25, **seg), orc.RefineParams(query=consensus, **ref), ok=ok)
+    for got in (fb, ex):
+        assert np.array_equal(got.status, status), np.flatnonzero(got.status != status)
+        good, rep = status == 0, (status == 0) | (status == 6)
+        assert _same(got.fpt[good], fpt[good]) and _same(got.dwell[good], dwell[good])
+        assert _same(got.stats[rep], stats[rep]) and _same(got.refine_idx[rep], idx[rep])
+        assert np.isnan(got.fpt[~good]).all() and (got.dwell[~good] == 0).all()
+        assert (got.refine_idx[~rep] == -1).all() and np.isnan(got.stats[~rep]).all()
+    assert (status == 0).sum() > 250 and (status == 6).sum() > 50 and status[3] == 1

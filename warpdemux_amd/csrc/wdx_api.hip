@@ -379,7 +379,7 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws})
         b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -627,6 +627,11 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
         if ((rc = fill_refine_dev(*rp, (const double *)ctx->ref_buf.p, (int32_t *)((unsigned char *)ctx->ref_buf.p + qb),
                                   &rf)))
             return rc;
+        // hand-over records of the fast kernels (state 0 = untouched)
+        const size_t wb = (size_t)fingerprint_refine_ws_bytes(n_reads);
+        if ((rc = ctx->ref_ws.ensure(wb ? wb : 8))) return rc;
+        WDX_HIP_TRY(hipMemsetAsync(ctx->ref_ws.p, 0, wb, s));
+        set_refine_ws(rf, ctx->ref_ws.p);
     }
     // only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
     // file_proc.py:244-260; the kernels never read outside [start, stop))

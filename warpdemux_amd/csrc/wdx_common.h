@@ -118,6 +118,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        MainEvents *main_ev = nullptr,
                        double *d_big = nullptr /* fingerprint_big_bytes(max_len) bytes, or null */);
 int64_t fingerprint_workspace_bytes(int64_t n_reads);
+// device bytes of the fast kernels' hand-over records for the refinement branch (RefineDev::ws), zero-initialised
+int64_t fingerprint_refine_ws_bytes(int64_t n_reads);
+void set_refine_ws(struct RefineDev *rf, void *d_ws);
 // device bytes the exact kernel needs for the score curves of windows beyond its LDS capacity (0 when max_len fits)
 int64_t fingerprint_big_bytes(int64_t max_len);
 int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream);

@@ -51,6 +51,7 @@ struct wdx_ctx {
     wdx::Buffer refs_pad, refs_T, refs_nan;
     // host-buffer call workspaces
     wdx::Buffer in0, in1, in2, in3, out0, out1, out2, out3, tmp0, tmp1, tmp2, scratch, fp_ws, svm_buf, ref_buf;
+    wdx::Buffer ref_ws;  // refinement branch: the fast kernels' hand-over records (fingerprint_refine_ws_bytes)
     wdx::Buffer fp_big;  // score curves of adapter windows beyond the exact kernel's LDS capacity (fingerprint_big_bytes)
     wdx::PinnedBuffer pin_in, pin_out;  // staging of small (live-tick sized) host-buffer calls
     int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes

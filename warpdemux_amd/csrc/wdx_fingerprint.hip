@@ -51,7 +51,19 @@ struct RefineDev {
     int ub_start, lb_end, ub_end;
     int E2;                // barcode_num_events[0]
     int32_t *idx;          // (n_reads, 3) seg_cons_query_start, seg_cons_query_end, sig_barcode_start; nullable
+    unsigned char *ws;     // n_reads RefineRec (device): the fast kernels' hand-over to fingerprint_refine_tail_kernel;
+                           // null -> the refinement branch runs on the exact kernel only
 };
+// What a fast kernel leaves behind for a read of the refinement branch: the adapter's segmentation (bit-identical to
+// the exact kernel's) and the clip bounds, so that the tail kernel can re-create the clipped samples of the barcode.
+struct RefineRec {
+    int32_t state;         // 0 untouched, 1 segmented by a fast kernel (pending), 2 handed on to the exact kernel
+    int32_t n;             // adapter window length
+    float lo, hi;          // clip bounds
+    int32_t cpts[132];     // nseg + 1 boundaries (nseg <= 128)
+    double ev[128];        // nseg event means
+};
+static_assert(sizeof(RefineRec) == 1568, "fingerprint_refine_ws_bytes");
 constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
 constexpr int kRefineMaxSeries = 128;
 
@@ -793,11 +805,15 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
 // three fronts of (cost, sqrt(cost)) pairs rotate through LDS, and what the back-trace needs -- argmin of the
 // three predecessors' sqrt'ed costs per cell, first minimum -- is kept as 2-bit codes, 16 per word, one row of
 // words per thread.  scratch: >= 3*(nq+1)*16 + nq*ceil(nseries/16)*4 bytes of LDS (the t-score tile buffers).
-template <int BLOCK>
-__device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *scores, unsigned char *state,
-                               const int ns, const int W, const int n, const float *sig, int *cpts, double *ev,
+// `prep(sbs, ns2, scores_tail, sig_tail)` is called (block-uniform) once the barcode's first sample `sbs` is known and
+// hands back the score curve and the clipped samples FROM `sbs` ON: the exact kernel has both in LDS already
+// (scores + sbs, sig + sbs); fingerprint_refine_tail_kernel -- the refinement behind the fast kernels -- loads and
+// scores only that tail.  Returning false leaves the read untouched (the caller hands it on).
+template <int BLOCK, class Prep>
+__device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *state,
+                               const int ns, const int W, const int n, int *cpts, double *ev,
                                double *zz, double *tmp, unsigned char *scratch, unsigned *hist, FpShared &sh,
-                               const int nseg) {
+                               const int nseg, Prep prep) {
     const int tid = threadIdx.x;
     const wdx_seg_params &P = A.p;
     const RefineDev &R = A.rf;
@@ -944,18 +960,21 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, const double *s
     }
     int nseg2 = 0, it2 = 0;
     const int n_end2 = ns2 + 2 * P.running_stat_width;
+    const double *sc_t = nullptr;
+    const float *sg_t = nullptr;
+    if (!prep(sbs, ns2, sc_t, sg_t)) return;
     {
         // a last boundary beyond the slice (window width shrunk below the configured one): the Cython loop of
         // compute_base_means indexes out of bounds -> exception -> "unknown"; checked BEFORE the means are summed
         if (n_end2 != n - sbs) {
             // still "event segmentation failed" when the tail has too few peaks (that return comes first)
-            const int st0 = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2,
-                                              false, sig + sbs, min(n_end2, n - sbs), cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
+            const int st0 = fp_segment<BLOCK>(sc_t, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2,
+                                              false, sg_t, min(n_end2, n - sbs), cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
             finish(st0 == WDX_READ_FAIL_SEGMENT ? WDX_READ_FAIL_SEGMENT : WDX_READ_FAIL_UNKNOWN, false);
             return;
         }
-        const int st = fp_segment<BLOCK>(scores + sbs, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2, false,
-                                         sig + sbs, n_end2, cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
+        const int st = fp_segment<BLOCK>(sc_t, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2, false,
+                                         sg_t, n_end2, cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
         if (st != WDX_READ_OK) {
             finish(st, false);
             return;
@@ -1211,8 +1230,12 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     }
     WDX_STAMP(7);
     if (A.rf.query) {
-        fp_refine_tail<BLOCK>(A, r, scores, state, ns, W, n, sig, cpts, ev, zz, tmp, reinterpret_cast<unsigned char *>(Mt),
-                              hist, sh, nseg);
+        fp_refine_tail<BLOCK>(A, r, state, ns, W, n, cpts, ev, zz, tmp, reinterpret_cast<unsigned char *>(Mt), hist, sh, nseg,
+                              [&](int sbs, int, const double *&sc_t, const float *&sg_t) {
+                                  sc_t = scores + sbs;   // the adapter pass's score curve and clipped samples are still here
+                                  sg_t = sig + sbs;
+                                  return true;
+                              });
         return;
     }
 
@@ -1337,6 +1360,108 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_big_kernel(FpArgs A, const 
     }
 }
 
+// The refinement branch behind the FAST kernels (round 3): a fast kernel segments the adapter (RefineRec), this kernel
+// does everything after it -- adapter statistics, the subsequence match, and the barcode's own segmentation, for
+// which it loads and scores ONLY the samples from `sig_barcode_start` on (re-clipped with the recorded bounds: the
+// same v_med3_f32 on the same values; the window statistics are the exact kernel's operations).  One 256-thread
+// workgroup per read, ~36 KB of LDS (four per CU).  A barcode tail beyond kTailCap samples is handed to the exact
+// kernel, which runs after this one.
+constexpr int kTailCap = 2048;
+static size_t refine_tail_lds_bytes() {
+    size_t b = (size_t)kSegCap * 8 * 3 + sizeof(FpShared) + 256 * 4 + (size_t)(kSegCap + 1) * 4;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)(kTailCap + 64) * 4 + (size_t)kTailCap * 8 + (size_t)kTailCap;
+    return (b + 15) & ~(size_t)15;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A, unsigned *slow_count, int32_t *slow_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int64_t r = A.block_base + blockIdx.x;
+    if (r >= A.n_reads) return;
+    RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
+    if (rec->state != 1) return;  // not segmented by a fast kernel: the exact kernel takes (or has reported) this read
+    const wdx_seg_params &P = A.p;
+    double *ev = reinterpret_cast<double *>(smem);
+    double *zz = ev + kSegCap, *tmp = zz + kSegCap;
+    FpShared &sh = *reinterpret_cast<FpShared *>(tmp + kSegCap);
+    unsigned *hist = reinterpret_cast<unsigned *>(&sh + 1);
+    int *cpts = reinterpret_cast<int *>(hist + 256);
+    unsigned char *T = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
+    double *t_scores = reinterpret_cast<double *>(T);                      // kTailCap (the subsequence DP's scratch first)
+    float *t_sig = reinterpret_cast<float *>(t_scores + kTailCap);         // kTailCap + 64
+    unsigned char *state = reinterpret_cast<unsigned char *>(t_sig + kTailCap + 64);  // kTailCap
+    const int n = rec->n, nseg = P.num_events + 1, W = P.running_stat_width;
+    for (int s = tid; s < nseg; s += BLOCK) ev[s] = rec->ev[s];
+    for (int s = tid; s <= nseg; s += BLOCK) cpts[s] = rec->cpts[s];
+    const float lo = rec->lo, hi = rec->hi;
+    __syncthreads();
+    const int64_t row_off = A.row_off ? A.row_off[r] : r * A.stride;
+    int64_t start = (int64_t)A.a_start[r] - P.padding;
+    if (start < 0) start = 0;
+    const float *__restrict__ src = A.sig + row_off + start;
+    const int ns = n - 2 * W;
+    fp_refine_tail<BLOCK>(A, r, state, ns, W, n, cpts, ev, zz, tmp, T, hist, sh, nseg,
+                          [&](int sbs, int ns2, const double *&sc_t, const float *&sg_t) -> bool {
+        const int nt = n - sbs;  // samples of the barcode tail
+        if (nt > kTailCap || nt < 0) {  // block-uniform: hand the whole read to the exact kernel
+            if (tid == 0) {
+                rec->state = 2;
+                slow_list[atomicAdd(slow_count, 1u)] = (int32_t)r;
+            }
+            return false;
+        }
+        for (int i = tid; i < nt; i += BLOCK) t_sig[i] = __builtin_amdgcn_fmed3f(src[sbs + i], lo, hi);
+        __syncthreads();
+        // windowed t-statistic of the tail (_c_segmentation.pyx:124-161; fp_process_read's operations, both windows per
+        // position instead of a staged tile: the tail is a thousand positions)
+        const double Wd = (double)W;
+        for (int pos = tid; pos < ns2; pos += BLOCK) {
+            double mv[2], vv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = pos + h * W;
+                double m = 0.0;
+                for (int k = 0; k < W; ++k) m += (double)t_sig[q + k];
+                m /= Wd;
+                double v = 0.0;
+                for (int k = 0; k < W; ++k) {
+                    const double df = (double)t_sig[q + k] - m;
+                    v += df * df;
+                }
+                mv[h] = m;
+                vv[h] = v;
+            }
+            const double vs = vv[0] + vv[1];
+            double sc;
+            if (vs == 0) sc = 0.0;
+            else if (mv[0] > mv[1]) sc = (mv[0] - mv[1]) / sqrt(vs);
+            else sc = (mv[1] - mv[0]) / sqrt(vs);
+            t_scores[pos] = sc;
+        }
+        __syncthreads();
+        sc_t = t_scores;
+        sg_t = t_sig;
+        return true;
+    });
+}
+
+static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list, hipStream_t stream) {
+    static LdsAttr attr;
+    const size_t lds = refine_tail_lds_bytes();
+    if (int rc = attr.ensure(fingerprint_refine_tail_kernel<256>, lds)) return rc;
+    const int64_t slice = 1 << 22;
+    for (int64_t base = 0; base < A.n_reads; base += slice) {
+        const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
+        A.block_base = base;
+        hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds, stream, A, slow_count,
+                           slow_list);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+int64_t fingerprint_refine_ws_bytes(int64_t n_reads) { return (int64_t)sizeof(RefineRec) * (n_reads > 0 ? n_reads : 0); }
+
 #include "wdx_fingerprint_fast.inc"
 
 static size_t fp_lds_bytes(int cap) {
@@ -1410,11 +1535,12 @@ int fill_refine_dev(const wdx_refine_params &rp, const double *d_query, int32_t 
         return WDX_ERR_INVALID;
     }
     RefineDev *r = new RefineDev{d_query, rp.n_query, rp.subseq_norm, rp.penalty, rp.psi[0], rp.psi[2],
-                                 rp.ub_start, rp.lb_end, rp.ub_end, rp.barcode_segm_events, d_idx};
+                                 rp.ub_start, rp.lb_end, rp.ub_end, rp.barcode_segm_events, d_idx, nullptr};
     *out = r;
     return WDX_SUCCESS;
 }
 void free_refine_dev(RefineDev *rf) { delete rf; }
+void set_refine_ws(RefineDev *rf, void *d_ws) { rf->ws = reinterpret_cast<unsigned char *>(d_ws); }
 
 // Self-test of the t-score's unscaled sqrt / quotient sequences (fast_sqrt_mid, fast_div_mid) against the
 // compiler's general float64 sqrt() and '/': same bits on the documented value range is what the fast path's
@@ -1517,7 +1643,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     // costs more than it saves: 1.62 against 1.99 M reads/s on the RNA002 triple (110, 15, 30))
     const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
-                         fast_combo(p) != 0 && (fast_combo(p) == 1 || !d_prof) && cap >= 512 && !knobs.exact_path && !rf;
+                         fast_combo(p) != 0 && (fast_combo(p) == 1 || !d_prof) && cap >= 512 && !knobs.exact_path &&
+                         (!rf || (rf->ws && !d_prof && p.num_events + 1 <= 128));
     if (fast_ok) {
         // A chain of launches, each handing what it cannot take to the next through device-side lists:
         //   main    one workgroup per read; the instantiation follows the longest adapter window of the batch:
@@ -1656,6 +1783,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         }
         WDX_HIP_TRY(hipGetLastError());
         if (!chain) return WDX_SUCCESS;  // (ablation timing of the main kernel: the lists are left unprocessed)
+        if (rf)  // the refinement branch of the reads a fast kernel segmented; its hand-overs join the slow list
+            if (int rc = launch_refine_tail(A, count, list, stream)) return rc;
         if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
                            : launch_fp_list<1024>(A, lds, count, list, stream))
             return rc;
