@@ -392,6 +392,80 @@ def secondary_regimes(device):
         "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
         "parity": bool(good) and all(v.get("parity") is True for v in hw.values())}
 
+    # ---- other shipped parameter triples on the fast kernels (device-resident fingerprint stage) + the tRNA config's
+    # consensus-refinement flow (host batch; HIP-event time of the fingerprint launches) ------------------------------
+    trip = {}
+    n_t = 262_144
+    for name, (E, d, W) in (("rna002_110_15_30", (110, 15, 30)), ("trna_120_9_18", (120, 9, 18))):
+        pt = sig_proc.SegParams(num_events=E, min_obs_per_base=d, running_stat_width=W, barcode_num_events=25)
+        engt = DemuxEngine(np.zeros((N_BARCODES, 25)), WINDOW, PENALTY, pt, device=device)
+        sg, of, s0, e0, _, mlen = engt.synth_packed(spec, 0, n_t)
+        for _ in range(2):
+            g = engt.fingerprint(sg, s0, e0, offsets=of, max_len=mlen)
+        sync()
+        walls = []
+        for _ in range(5):
+            sync()
+            t0 = time.perf_counter()
+            g = engt.fingerprint(sg, s0, e0, offsets=of, max_len=mlen)
+            sync()
+            walls.append(time.perf_counter() - t0)
+        ns_ = 4096
+        o_h = of[:ns_ + 1].cpu().numpy()
+        ofp, odw, ost, ostat = orc.fingerprint_packed(sg[:int(o_h[-1])].cpu().numpy(), o_h, s0[:ns_].cpu().numpy(), e0[:ns_].cpu().numpy(),
+                                                      orc.SegParams(num_events=E, min_obs_per_base=d, running_stat_width=W, barcode_num_events=25))
+        okt = ostat == 0
+        trip[name] = {"reads_per_s": n_t / (sum(walls) / len(walls)), "ms": 1e3 * sum(walls) / len(walls), "ms_min": 1e3 * min(walls),
+                      "reads": n_t, "parity_reads": ns_,
+                      "parity": bool(np.array_equal(g[3][:ns_].cpu().numpy(), ostat) and
+                                     np.array_equal(g[0][:ns_].cpu().numpy()[okt].view(np.uint64), ofp[okt].view(np.uint64)) and
+                                     np.array_equal(g[1][:ns_].cpu().numpy()[okt], odw[okt]))}
+        del sg, of, s0, e0, g
+        engt.close()
+    try:
+        cons = np.load(os.path.join(ROOT, "tests", "golden", "g8_refine.npz"))["consensus"]
+        nr = 8192
+        rows_r = []
+        for i in range(nr):
+            lv = np.concatenate([rng.normal(0, 1, int(rng.integers(2, 34))), cons, rng.normal(0, 1, 30)]) * 12.0 + 85.0
+            dwl = rng.integers(12, 60, lv.size)
+            rows_r.append((np.repeat(lv, dwl) + rng.normal(0, 1.5, int(dwl.sum()))).astype(np.float32))
+        st_r = max(x.size for x in rows_r)
+        mbr = np.full((nr, st_r), np.nan, dtype=np.float32)
+        for i, x in enumerate(rows_r):
+            mbr[i, :x.size] = x
+        asr = np.full(nr, 100, dtype=np.int32)
+        aer = np.array([x.size - 100 for x in rows_r], dtype=np.int32)
+        kwr = dict(min_obs_per_base=9, running_stat_width=18, num_events=120, barcode_num_events=25)
+        hp, hr = sig_proc.SegParams(**kwr), sig_proc.RefineParams(query=cons, barcode_segm_events=25, barcode_keep_events=25)
+        cdef = _lib.default_context(device)
+        Ll = _lib.load()
+        fr = sig_proc.fingerprint_refine_batch(mbr, asr, aer, hp, hr, device=device)
+        _lib.check(Ll.wdx_kernel_time_reset(cdef.handle))
+        _lib.check(Ll.wdx_kernel_timing(cdef.handle, 1))
+        for _ in range(3):
+            fr = sig_proc.fingerprint_refine_batch(mbr, asr, aer, hp, hr, device=device)
+        _lib.check(Ll.wdx_kernel_timing(cdef.handle, 0))
+        import ctypes as C
+        ms_, k_ = C.c_double(0), C.c_int64(0)
+        _lib.check(Ll.wdx_kernel_time(cdef.handle, _lib.K_FINGERPRINT, C.byref(ms_), C.byref(k_)))
+        ns_ = 1024
+        ofp, odw, ostt, oidx, ostat = orc.fingerprint_refine_batch(
+            mbr[:ns_], asr[:ns_], aer[:ns_], orc.SegParams(**kwr),
+            orc.RefineParams(query=cons, barcode_segm_events=25, barcode_keep_events=25))
+        okt = ostat == 0
+        trip["trna_refine_flow"] = {
+            "reads_per_s": nr / (ms_.value / 3 * 1e-3), "ms": ms_.value / 3, "reads": nr, "timing": "HIP events around the fingerprint launches (host copies excluded)",
+            "ok_reads": int((fr.status == 0).sum()), "consensus_outliers": int((fr.status == 6).sum()), "parity_reads": ns_,
+            "parity": bool(np.array_equal(fr.status[:ns_], ostat) and np.array_equal(fr.fpt[:ns_][okt].view(np.uint64), ofp[okt].view(np.uint64))
+                           and np.array_equal(fr.refine_idx[:ns_][okt], oidx[okt]))}
+    except OSError:
+        trip["trna_refine_flow"] = None
+    out["other_triples"] = {
+        "workload": "fingerprint stage of the other shipped parameter triples (num_events, min_obs_per_base, running_stat_width) on "
+                    "262 144 device-resident synthetic reads, and the tRNA config's consensus-refinement flow on 8 192 host reads",
+        **trip, "parity": all(v.get("parity") is True for v in trip.values() if isinstance(v, dict))}
+
     # ---- live (C5): ticks of 1 / 64 / 512 reads through the live shim, WDX6 shape and the shipped WDX6 shape ------
     live = {}
     for K, nYl in ((K_FPT, 6), (25, 1368)):
