@@ -186,6 +186,9 @@ int set_refs_locked(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_
         return WDX_SUCCESS;
     }
     ++ctx->refs_gen;
+    // a pipelined minibatch (wdx_demux_submit) may still be reading the set that is about to be rebuilt
+    for (wdx_ctx *S : ctx->slots)
+        if (S) WDX_HIP_TRY(hipStreamSynchronize(S->stream));
     // not set until every buffer below is rebuilt: a failure in the middle must not leave a stale hash over
     // freed or half-written buffers (a later call then reports WDX_ERR_NO_REFS instead of reading them)
     R.window = 0;
@@ -458,7 +461,7 @@ int wdx_set_refs(wdx_ctx *ctx, const double *Y, int64_t nY, int64_t L, int32_t w
     WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     if ((rc = use_stream(ctx, ctx->stream))) return rc;
-    for (wdx_ctx *S : ctx->slots)   // a pipelined minibatch may still be reading the set that is about to change
+    for (wdx_ctx *S : ctx->slots)   // (also when only window / penalty change: a slot copied them at its submit)
         if (S) WDX_HIP_TRY(hipStreamSynchronize(S->stream));
     return set_refs_locked(ctx, Y, nY, L, window, penalty, ctx->stream);
 }
