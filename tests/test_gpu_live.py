@@ -400,6 +400,38 @@ def test_ctx_synchronize_null_names_the_null_stream_and_the_context_stream():
     ctx.close()
 
 
+@pytest.mark.timeout(600)
+def test_two_ranks_reach_the_rccl_collective_init_through_the_c_abi():
+    """a communicator with more than one rank has never run.  A 1-GPU box cannot run one either (RCCL
+    refuses two ranks on one device), but it can run everything UP TO that refusal: two processes, wdx_comm_available
+    on both, the id drawn on rank 0 and broadcast, both ranks inside ncclCommInitRank -- whose bootstrap connects them
+    through the id before the device check -- and the failure raised on BOTH ranks, no hang, no silent
+    torch.distributed road.  Should this RCCL accept the duplicate device, the reduced histogram is checked instead."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_two_ranks.py")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    recs = []
+    for p in procs:
+        so, se = p.communicate(timeout=500)
+        assert p.returncode == 0, se[-3000:]
+        recs.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+    recs.sort(key=lambda r: r["rank"])
+    if "error" in recs[0] or "error" in recs[1]:
+        for r in recs:   # refused together, and for RCCL's reason
+            assert "error" in r and "ncclCommInitRank" in r["error"], recs
+    else:
+        for r in recs:
+            assert r["mode"] == "rccl" and r["rccl_ranks"] == 2 and r["counts"] == [3, 30, 200], recs
+
+
 @pytest.mark.timeout(900)
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (children before any

@@ -6,7 +6,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/isa_tile}
-SYM=_ZN3wdx23fingerprint_fast_kernelILi24ELb0EEEvNS_8FastArgsE
+SYM=_ZN3wdx23fingerprint_fast_kernelILi24ELb0ELi12ELi1EEEvNS_8FastArgsE
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -save-temps -Rpass-analysis=kernel-resource-usage"
 for V in approx exact; do
     D="$OUT/$V"
