@@ -53,7 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: C3 = 10 M at N=1, C4 = 5 M at N>1)")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+    ap.add_argument("--cpu-seconds", type=float, default=33.0,
                     help="time budget of the CPU baseline / parity gate (oracle on all host cores)")
     ap.add_argument("--parity-reads", type=int, default=1_000_000,
                     help="upper bound of reads verified against the oracle inside the time budget; a run with "
