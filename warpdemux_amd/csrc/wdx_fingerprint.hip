@@ -24,6 +24,7 @@
 #include "wdx_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace wdx {
 
@@ -57,13 +58,15 @@ struct RefineDev {
 // What a fast kernel leaves behind for a read of the refinement branch: the adapter's segmentation (bit-identical to
 // the exact kernel's) and the clip bounds, so that the tail kernel can re-create the clipped samples of the barcode.
 struct RefineRec {
-    int32_t state;         // 0 untouched, 1 segmented by a fast kernel (pending), 2 handed on to the exact kernel
+    int32_t state;         // 0 untouched, 1 segmented by a fast kernel, 3 matched (fingerprint_refine_match_kernel),
+                           // 4 reported by the match kernel, 2 handed on to the exact kernel (tail beyond kTailCap)
     int32_t n;             // adapter window length
     float lo, hi;          // clip bounds
     int32_t cpts[132];     // nseg + 1 boundaries (nseg <= 128)
     double ev[128];        // nseg event means
+    double m[8];           // RefineMatch of the match kernel (bit copy)
 };
-static_assert(sizeof(RefineRec) == 1568, "fingerprint_refine_ws_bytes");
+static_assert(sizeof(RefineRec) == 1632, "fingerprint_refine_ws_bytes");
 constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
 constexpr int kRefineMaxSeries = 128;
 
@@ -809,11 +812,17 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
 // hands back the score curve and the clipped samples FROM `sbs` ON: the exact kernel has both in LDS already
 // (scores + sbs, sig + sbs); fingerprint_refine_tail_kernel -- the refinement behind the fast kernels -- loads and
 // scores only that tail.  Returning false leaves the read untouched (the caller hands it on).
-template <int BLOCK, class Prep>
-__device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *state,
-                               const int ns, const int W, const int n, int *cpts, double *ev,
-                               double *zz, double *tmp, unsigned char *scratch, unsigned *hist, FpShared &sh,
-                               const int nseg, Prep prep) {
+// The branch comes in two halves so that the kernel behind the fast kernels can run them as two launches with very
+// different LDS needs (the match is pure latency and wants many resident workgroups; the barcode's segmentation
+// needs the tail's samples and scores): fp_refine_match -- adapter statistics, subsequence match, back-trace ->
+// RefineMatch (false: the read has been reported, nothing more to do) -- and fp_refine_finish.
+struct RefineMatch {
+    double mean, sd, ev_med, ev_mad, dt_med, dt_mad;
+    int32_t qs, qe, sbs, pad_;
+};
+template <int BLOCK>
+__device__ bool fp_refine_match(const FpArgs &A, const int64_t r, const int *cpts, double *ev, double *zz, double *tmp,
+                                unsigned char *scratch, FpShared &sh, const int nseg, RefineMatch &M) {
     const int tid = threadIdx.x;
     const wdx_seg_params &P = A.p;
     const RefineDev &R = A.rf;
@@ -837,7 +846,7 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *
         for (int s = tid; s < nseg; s += BLOCK) has_nan |= (ev[s] != ev[s]);
         if (__syncthreads_or(has_nan)) {
             finish(WDX_READ_FAIL_UNKNOWN, false);
-            return;
+            return false;
         }
     }
     // adapter statistics (sig_proc.py:486-494) and the shift / scale of both normalisations
@@ -868,7 +877,7 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *
         double c0 = 0.0, c1 = 1.0;
         if (R.norm == WDX_NORM_MEAN) { c0 = mean; c1 = sd; }
         else if (R.norm == WDX_NORM_MEDIAN) { c0 = ev_med; c1 = ev_mad; }
-        else if (R.norm != WDX_NORM_NONE) { finish(WDX_READ_FAIL_UNKNOWN, false); return; }
+        else if (R.norm != WDX_NORM_NONE) { finish(WDX_READ_FAIL_UNKNOWN, false); return false; }
         int bad = 0;
         for (int s = tid; s < nseg; s += BLOCK) {
             const double v = R.norm == WDX_NORM_NONE ? ev[s] : (ev[s] - c0) / c1;
@@ -877,7 +886,7 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *
         }
         if (__syncthreads_or(bad)) {  // a constant series (0/0): the library's behaviour on NaN is not restated
             finish(WDX_READ_FAIL_UNKNOWN, false);
-            return;
+            return false;
         }
     }
     // ---- subsequence DTW of the consensus query against the normalised event means ------------------------
@@ -951,6 +960,32 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *
     const int qs = sh.flag, qe = sh.count;
     const int sbs = cpts[qe];   // int(np.sum(adapter_dwell_times[:seg_query_end]))
     __syncthreads();            // cpts is rewritten below
+    M = RefineMatch{mean, sd, ev_med, ev_mad, dt_med, dt_mad, qs, qe, sbs, 0};
+    return true;
+}
+
+template <int BLOCK, class Prep>
+__device__ void fp_refine_finish(const FpArgs &A, const int64_t r, const RefineMatch &M, unsigned char *state, const int ns,
+                                 const int n, int *cpts, double *zz, unsigned *hist, FpShared &sh, Prep prep) {
+    const int tid = threadIdx.x;
+    const wdx_seg_params &P = A.p;
+    const RefineDev &R = A.rf;
+    const int K = P.barcode_num_events;
+    auto finish = [&](int st, bool with_stats) {
+        if (st != WDX_READ_OK) {
+            for (int i = tid; i < K; i += BLOCK) {
+                if (A.fpt) A.fpt[r * K + i] = __builtin_nan("");
+                if (A.dwell) A.dwell[r * K + i] = 0;
+            }
+            if (!with_stats) {
+                if (A.stats && tid < 6) A.stats[r * 6 + tid] = __builtin_nan("");
+                if (R.idx && tid < 3) R.idx[r * 3 + tid] = -1;
+            }
+        }
+        if (tid == 0) A.status[r] = st;
+    };
+    const double mean = M.mean, sd = M.sd, ev_med = M.ev_med, ev_mad = M.ev_mad, dt_med = M.dt_med, dt_mad = M.dt_mad;
+    const int qs = M.qs, qe = M.qe, sbs = M.sbs;
     // ---- the barcode tail: discrepenacy_curve_to_cpts(adapter_scores[sbs:], E2, config d, config W, False) -----
     int ns2 = ns - sbs;
     if (ns2 < 0) ns2 = 0;
@@ -1012,6 +1047,18 @@ __device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *
         if (A.dwell) A.dwell[r * K + i] = (int64_t)(cpts[s + 1] - cpts[s]);
     }
     finish(WDX_READ_OK, true);
+}
+
+
+template <int BLOCK, class Prep>
+__device__ void fp_refine_tail(const FpArgs &A, const int64_t r, unsigned char *state,
+                               const int ns, const int W, const int n, int *cpts, double *ev,
+                               double *zz, double *tmp, unsigned char *scratch, unsigned *hist, FpShared &sh,
+                               const int nseg, Prep prep) {
+    (void)W;
+    RefineMatch M;
+    if (!fp_refine_match<BLOCK>(A, r, cpts, ev, zz, tmp, scratch, sh, nseg, M)) return;
+    fp_refine_finish<BLOCK>(A, r, M, state, ns, n, cpts, zz, hist, sh, prep);
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
@@ -1360,19 +1407,57 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_big_kernel(FpArgs A, const 
     }
 }
 
-// The refinement branch behind the FAST kernels (round 3): a fast kernel segments the adapter (RefineRec), this kernel
-// does everything after it -- adapter statistics, the subsequence match, and the barcode's own segmentation, for
-// which it loads and scores ONLY the samples from `sig_barcode_start` on (re-clipped with the recorded bounds: the
-// same v_med3_f32 on the same values; the window statistics are the exact kernel's operations).  One 256-thread
-// workgroup per read, ~36 KB of LDS (four per CU).  A barcode tail beyond kTailCap samples is handed to the exact
-// kernel, which runs after this one.
+// The refinement branch behind the FAST kernels (round 3): a fast kernel segments the adapter (RefineRec) and two
+// kernels do everything after it with fp_refine_match / fp_refine_finish, the exact kernel's own code:
+//   fingerprint_refine_match_kernel  adapter statistics, subsequence DP, back-trace.  Pure latency (207 fronts of a DP
+//                                    with <= 97 active threads, single-thread sums and walk): 128 threads and ~17 KB
+//                                    of LDS per read, so that many reads are resident (the one-kernel form at 36 KB
+//                                    was 1.8x slower at half its occupancy);
+//   fingerprint_refine_tail_kernel   the barcode's own segmentation: loads ONLY the samples from sig_barcode_start on,
+//                                    re-clips them with the recorded bounds (the same v_med3_f32 on the same values),
+//                                    computes their t-scores with the exact kernel's operations and segments them.
+// A barcode tail beyond kTailCap samples is handed to the exact kernel, which runs after these two.
 constexpr int kTailCap = 2048;
+constexpr int kMatchScratch = 3 * (kRefineMaxQuery + 1) * 16 + kRefineMaxQuery * ((kRefineMaxSeries + 15) / 16) * 4;
+static size_t refine_match_lds_bytes() {
+    size_t b = (size_t)kSegCap * 8 * 3 + sizeof(FpShared) + (size_t)(kSegCap + 1) * 4;
+    b = (b + 15) & ~(size_t)15;
+    return (b + kMatchScratch + 15) & ~(size_t)15;
+}
 static size_t refine_tail_lds_bytes() {
-    size_t b = (size_t)kSegCap * 8 * 3 + sizeof(FpShared) + 256 * 4 + (size_t)(kSegCap + 1) * 4;
+    size_t b = (size_t)kSegCap * 8 + sizeof(FpShared) + 256 * 4 + (size_t)(kSegCap + 1) * 4;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)(kTailCap + 64) * 4 + (size_t)kTailCap * 8 + (size_t)kTailCap;
     return (b + 15) & ~(size_t)15;
 }
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fingerprint_refine_match_kernel(FpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int64_t r = A.block_base + blockIdx.x;
+    if (r >= A.n_reads) return;
+    RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
+    if (rec->state != 1) return;  // not segmented by a fast kernel: the exact kernel takes (or has reported) this read
+    double *ev = reinterpret_cast<double *>(smem);
+    double *zz = ev + kSegCap, *tmp = zz + kSegCap;
+    FpShared &sh = *reinterpret_cast<FpShared *>(tmp + kSegCap);
+    int *cpts = reinterpret_cast<int *>(&sh + 1);
+    unsigned char *scratch = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
+    const int nseg = A.p.num_events + 1;
+    for (int s = tid; s < nseg; s += BLOCK) ev[s] = rec->ev[s];
+    for (int s = tid; s <= nseg; s += BLOCK) cpts[s] = rec->cpts[s];
+    __syncthreads();
+    RefineMatch M;
+    const bool go = fp_refine_match<BLOCK>(A, r, cpts, ev, zz, tmp, scratch, sh, nseg, M);
+    if (tid == 0) {
+        if (go) {
+            static_assert(sizeof(RefineMatch) == 64, "RefineRec::m");
+            memcpy(rec->m, &M, sizeof(M));
+        }
+        rec->state = go ? 3 : 4;
+    }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A, unsigned *slow_count, int32_t *slow_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1380,29 +1465,27 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
     const int64_t r = A.block_base + blockIdx.x;
     if (r >= A.n_reads) return;
     RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
-    if (rec->state != 1) return;  // not segmented by a fast kernel: the exact kernel takes (or has reported) this read
+    if (rec->state != 3) return;
     const wdx_seg_params &P = A.p;
-    double *ev = reinterpret_cast<double *>(smem);
-    double *zz = ev + kSegCap, *tmp = zz + kSegCap;
-    FpShared &sh = *reinterpret_cast<FpShared *>(tmp + kSegCap);
+    double *zz = reinterpret_cast<double *>(smem);
+    FpShared &sh = *reinterpret_cast<FpShared *>(zz + kSegCap);
     unsigned *hist = reinterpret_cast<unsigned *>(&sh + 1);
     int *cpts = reinterpret_cast<int *>(hist + 256);
     unsigned char *T = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
-    double *t_scores = reinterpret_cast<double *>(T);                      // kTailCap (the subsequence DP's scratch first)
+    double *t_scores = reinterpret_cast<double *>(T);                      // kTailCap
     float *t_sig = reinterpret_cast<float *>(t_scores + kTailCap);         // kTailCap + 64
     unsigned char *state = reinterpret_cast<unsigned char *>(t_sig + kTailCap + 64);  // kTailCap
-    const int n = rec->n, nseg = P.num_events + 1, W = P.running_stat_width;
-    for (int s = tid; s < nseg; s += BLOCK) ev[s] = rec->ev[s];
-    for (int s = tid; s <= nseg; s += BLOCK) cpts[s] = rec->cpts[s];
+    RefineMatch M;
+    memcpy(&M, rec->m, sizeof(M));
+    const int n = rec->n, W = P.running_stat_width;
     const float lo = rec->lo, hi = rec->hi;
-    __syncthreads();
     const int64_t row_off = A.row_off ? A.row_off[r] : r * A.stride;
     int64_t start = (int64_t)A.a_start[r] - P.padding;
     if (start < 0) start = 0;
     const float *__restrict__ src = A.sig + row_off + start;
     const int ns = n - 2 * W;
-    fp_refine_tail<BLOCK>(A, r, state, ns, W, n, cpts, ev, zz, tmp, T, hist, sh, nseg,
-                          [&](int sbs, int ns2, const double *&sc_t, const float *&sg_t) -> bool {
+    fp_refine_finish<BLOCK>(A, r, M, state, ns, n, cpts, zz, hist, sh,
+                            [&](int sbs, int ns2, const double *&sc_t, const float *&sg_t) -> bool {
         const int nt = n - sbs;  // samples of the barcode tail
         if (nt > kTailCap || nt < 0) {  // block-uniform: hand the whole read to the exact kernel
             if (tid == 0) {
@@ -1447,14 +1530,16 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
 }
 
 static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list, hipStream_t stream) {
-    static LdsAttr attr;
-    const size_t lds = refine_tail_lds_bytes();
-    if (int rc = attr.ensure(fingerprint_refine_tail_kernel<256>, lds)) return rc;
+    static LdsAttr attr_m, attr_t;
+    const size_t lds_m = refine_match_lds_bytes(), lds_t = refine_tail_lds_bytes();
+    if (int rc = attr_m.ensure(fingerprint_refine_match_kernel<128>, lds_m)) return rc;
+    if (int rc = attr_t.ensure(fingerprint_refine_tail_kernel<256>, lds_t)) return rc;
     const int64_t slice = 1 << 22;
     for (int64_t base = 0; base < A.n_reads; base += slice) {
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
-        hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds, stream, A, slow_count,
+        hipLaunchKernelGGL((fingerprint_refine_match_kernel<128>), dim3((unsigned)n), dim3(128), lds_m, stream, A);
+        hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
                            slow_list);
     }
     WDX_HIP_TRY(hipGetLastError());
