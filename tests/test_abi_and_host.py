@@ -44,6 +44,15 @@ def test_no_silent_fallback_without_gpu():
         pdist.distance_matrix_to(X, Y, window=15, penalty=0.1, n_jobs=1)
     with pytest.raises(_lib.WdxError):
         sig_proc.fingerprint_batch(np.zeros((2, 100), np.float32), [0, 0], [100, 100], sig_proc.SegParams())
+    # the pipelined worker API and its page-locked buffers: no host fallback either
+    from warpdemux_amd import pipeline
+
+    with pytest.raises(_lib.WdxError):
+        pipeline.pinned_empty((4, 16), np.float32)
+    with pytest.raises(_lib.WdxError):
+        pipeline.MinibatchPipeline(np.zeros((3, 25)), 15, 0.1)
+    L = _lib.load()
+    assert L.wdx_comm_available() in (0, _lib.WDX_ERR_NO_DEVICE)     # a local probe: never needs a device
 
 
 def test_reference_error_behaviour_is_mirrored():
