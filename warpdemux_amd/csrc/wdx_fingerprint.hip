@@ -1651,7 +1651,8 @@ int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 16 * (n_reads
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
 //   2: W = 18, d <= 9  (tRNA triple: 120, 9, 18; the tRNA config itself also refines -> exact kernel)
 //   3: W = 30, d <= 17 (RNA002 triple: 110, 15, 30)
-// 2 and 3 run the 6144-sample instantiation as main kernel and the 8192-sample one for longer windows and retries.
+// 2 runs the 5120-sample instantiation as main kernel for large batches (then 6144 and 8192 behind it, like 1); 3 the
+// 6144-sample one, and the 8192-sample one for longer windows and retries.
 static int fast_combo(const wdx_seg_params &p) {
     if (p.min_obs_per_base < 1) return 0;
     if (p.running_stat_width == 12 && p.min_obs_per_base <= 9) return 1;
@@ -1752,7 +1753,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const int nbt = combo == 3 ? 2 : 1;
         int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
         if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
-        if (combo != 1) capF = 6144;  // the other triples: one main instantiation
+        if (combo == 2) capF = large_batch ? 5120 : 6144;  // width 18: five workgroups per CU too (91 VGPRs)
+        if (combo == 3) capF = 6144;  // width 30 / reach 17: 115 VGPRs, four waves per SIMD either way
         // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
         // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
@@ -1780,10 +1782,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
         int slot = 0;
         if (combo == 2) {
-            kern = fingerprint_fast_kernel<kNptLarge, false, 18, 1>;
+            kern = capF == 5120 ? fingerprint_fast_kernel<kNptMid, false, 18, 1> : fingerprint_fast_kernel<kNptLarge, false, 18, 1>;
             kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 18, 1>;
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, 18, 1>;
-            slot = 2;
+            slot = capF == 5120 ? 1 : 2;
         } else if (combo == 3) {
             kern = fingerprint_fast_kernel<kNptLarge, false, 30, 2>;
             kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 30, 2>;
