@@ -299,6 +299,12 @@ def secondary_regimes(device):
     out = {}
     rng = np.random.default_rng(0)
     tdev = torch.device("cuda", device)
+    t_leg = [time.perf_counter()]
+
+    def leg_done(name):   # wall time per leg on stderr: a slow box explains itself
+        now = time.perf_counter()
+        print("[bench] secondary.%s: %.1f s" % (name, now - t_leg[0]), file=sys.stderr, flush=True)
+        t_leg[0] = now
 
     def sync():
         torch.cuda.synchronize(tdev)
@@ -342,6 +348,7 @@ def secondary_regimes(device):
                  "parity_pairs": int(rows * nY)}
     del X, d, am
     eng.close()
+    leg_done("r2")
 
     # ---- host_minibatch: what file_proc.py:418-450 would pass -- 1000 x 10 000 float32 rows, PCIe included -----
     spec = synth.SynthSpec(n_barcodes=N_BARCODES)
@@ -368,14 +375,19 @@ def secondary_regimes(device):
         "parity": bool(np.array_equal(fb.status, ostatus) and np.array_equal(fb.fpt[ook], ofpt[ook])
                        and np.array_equal(fb.dwell[ook], odw[ook]) and np.array_equal(Dm.view(np.uint32), oD.view(np.uint32)))}
 
+    leg_done("host_minibatch")
     # ---- host_workers: the reference's real calling pattern -- P forked workers x 1000-read minibatches sharing this GPU
     # (file_proc.py:380-454, 1197-1243).  Fresh interpreters (tools/host_workers.py forks before any GPU call); this
     # process keeps its context but is idle meanwhile.
     hw = {}
-    for mode, refill, Ps in (("sync", False, (1, 4, 8, 16)), ("pipe", False, (1, 4, 8, 16)), ("pipe", True, (4,))):
+    t_hw = time.perf_counter()
+    for mode, refill, Ps in (("pipe", False, (1, 4, 8)), ("sync", False, (1, 4, 16)), ("pipe", True, (4,))):
         for P in Ps:
             cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
                    "--seconds", "2"] + (["--refill"] if refill else [])
+            if time.perf_counter() - t_hw > 75.0:   # a slow box must not stretch the default run: the rest is skipped, and says so
+                hw["%s%s_P%d" % (mode, "_refill" if refill else "", P)] = {"skipped": "leg budget of 75 s spent"}
+                continue
             try:
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
                 rec = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
@@ -390,8 +402,9 @@ def secondary_regimes(device):
                     "worker copies a fresh minibatch into the buffer before every call",
         "host_cpus": effective_cores(), **hw,
         "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
-        "parity": bool(good) and all(v.get("parity") is True for v in hw.values())}
+        "parity": bool(good) and all(v.get("parity") is True for v in hw.values() if "skipped" not in v)}
 
+    leg_done("host_workers")
     # ---- other shipped parameter triples on the fast kernels (device-resident fingerprint stage) + the tRNA config's
     # consensus-refinement flow (host batch; HIP-event time of the fingerprint launches) ------------------------------
     trip = {}
@@ -454,10 +467,31 @@ def secondary_regimes(device):
             mbr[:ns_], asr[:ns_], aer[:ns_], orc.SegParams(**kwr),
             orc.RefineParams(query=cons, barcode_segm_events=25, barcode_keep_events=25))
         okt = ostat == 0
+        # the same flow device-resident at 8x the reads (wdx_fingerprint_refine_dev on the 8 192 rows repeated)
+        engr = DemuxEngine(np.zeros((N_BARCODES, 25)), WINDOW, PENALTY, hp, device=device)
+        rep = 8
+        dmb = torch.from_numpy(mbr).to(tdev).repeat(rep, 1)
+        das, dae = torch.from_numpy(asr).to(tdev).repeat(rep), torch.from_numpy(aer).to(tdev).repeat(rep)
+        for _ in range(2):
+            gdev = engr.fingerprint_refine(dmb, das, dae, hr, stride=st_r, max_len=int(aer.max()) + 100)
+        sync()
+        wl = []
+        for _ in range(3):
+            sync()
+            t0 = time.perf_counter()
+            gdev = engr.fingerprint_refine(dmb, das, dae, hr, stride=st_r, max_len=int(aer.max()) + 100)
+            sync()
+            wl.append(time.perf_counter() - t0)
+        dev_same = bool(np.array_equal(gdev[4][:nr].cpu().numpy(), fr.status) and
+                        np.array_equal(gdev[0][:nr].cpu().numpy().view(np.uint64), fr.fpt.view(np.uint64)))
+        del dmb, gdev
+        engr.close()
         trip["trna_refine_flow"] = {
             "reads_per_s": nr / (ms_.value / 3 * 1e-3), "ms": ms_.value / 3, "reads": nr, "timing": "HIP events around the fingerprint launches (host copies excluded)",
+            "device_resident": {"reads": nr * rep, "reads_per_s": nr * rep / (sum(wl) / len(wl)), "ms": 1e3 * sum(wl) / len(wl),
+                                "same_bits_as_host_call": dev_same},
             "ok_reads": int((fr.status == 0).sum()), "consensus_outliers": int((fr.status == 6).sum()), "parity_reads": ns_,
-            "parity": bool(np.array_equal(fr.status[:ns_], ostat) and np.array_equal(fr.fpt[:ns_][okt].view(np.uint64), ofp[okt].view(np.uint64))
+            "parity": bool(dev_same and np.array_equal(fr.status[:ns_], ostat) and np.array_equal(fr.fpt[:ns_][okt].view(np.uint64), ofp[okt].view(np.uint64))
                            and np.array_equal(fr.refine_idx[:ns_][okt], oidx[okt]))}
     except OSError:
         trip["trna_refine_flow"] = None
@@ -466,6 +500,7 @@ def secondary_regimes(device):
                     "262 144 device-resident synthetic reads, and the tRNA config's consensus-refinement flow on 8 192 host reads",
         **trip, "parity": all(v.get("parity") is True for v in trip.values() if isinstance(v, dict))}
 
+    leg_done("other_triples")
     # ---- live (C5): ticks of 1 / 64 / 512 reads through the live shim, WDX6 shape and the shipped WDX6 shape ------
     live = {}
     for K, nYl in ((K_FPT, 6), (25, 1368)):
@@ -496,6 +531,7 @@ def secondary_regimes(device):
                                "host buffers in/out through pinned staging on the context's stream (reference: 4.3 ms + 13.5 ms per read)",
                    **live}
 
+    leg_done("live")
     # ---- dtw_svm_predict: WDX4-shaped DTW_SVM (851 x 25-pt training rows, 5 classes) on host fingerprints -------
     try:
         from sklearn.svm import SVC
@@ -528,6 +564,7 @@ def secondary_regimes(device):
             "parity_tolerance": 1e-5}
     except ImportError:
         out["dtw_svm_predict"] = None
+    leg_done("dtw_svm_predict")
     return out
 
 

@@ -200,6 +200,16 @@ int wdx_fingerprint_refine_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads
                                  const wdx_seg_params *p, const wdx_refine_params *rp, double *fpt, int64_t *dwell,
                                  double *stats, int32_t *refine_idx, int32_t *status);
 
+/* Device-resident form of the refinement branch: inputs and outputs as in wdx_fingerprint_dev (d_fpt / d_dwell have
+ * K = rp->barcode_keep_events columns), d_refine_idx (n_reads, 3) int32 on the device; rp and its query are HOST
+ * memory (copied before the call returns).  Enqueued on `stream`; no synchronisation. */
+int wdx_fingerprint_refine_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                               const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
+                               const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
+                               const wdx_seg_params *p, const wdx_refine_params *rp, double *d_fpt,
+                               int64_t *d_dwell, double *d_stats, int32_t *d_refine_idx, int32_t *d_status,
+                               void *stream);
+
 /* ---- fused path: raw adapter rows -> fingerprint -> DTW to the resident refs -> call ------ */
 
 /* As wdx_fingerprint_dev, then DTW of every successful read against the resident refs.

@@ -213,3 +213,34 @@ def test_refinement_behind_the_fast_kernels_matches_the_exact_kernel_and_the_ora
         assert np.isnan(got.fpt[~good]).all() and (got.dwell[~good] == 0).all()
         assert (got.refine_idx[~rep] == -1).all() and np.isnan(got.stats[~rep]).all()
     assert (status == 0).sum() > 250 and (status == 6).sum() > 50 and status[3] == 1
+
+
+def test_refinement_device_resident_entry_point(golden_dir):
+    """wdx_fingerprint_refine_dev (DemuxEngine.fingerprint_refine): device tensors in and out, same bits as the host
+    batch call, minibatch and packed layouts."""
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]
+    mb, a_s, a_e = _reads(consensus, 300, 23)
+    seg = dict(min_obs_per_base=9, running_stat_width=18, num_events=120)
+    hp = sig_proc.SegParams(barcode_num_events=25, **seg)
+    hr = sig_proc.RefineParams(query=consensus, barcode_segm_events=25, barcode_keep_events=25)
+    ref = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, hp, hr)
+    eng = DemuxEngine(np.zeros((4, 25)), 15, 0.1, hp)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    lens = (a_e + 100).astype(np.int64)
+    for layout in ("minibatch", "packed"):
+        if layout == "minibatch":
+            out = eng.fingerprint_refine(d(mb), d(a_s), d(a_e), hr, stride=mb.shape[1], max_len=int(lens.max()))
+        else:
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            packed = np.concatenate([mb[i, :lens[i]] for i in range(mb.shape[0])])
+            out = eng.fingerprint_refine(d(packed), d(a_s), d(a_e), hr, offsets=d(off), max_len=int(lens.max()))
+        torch.cuda.synchronize()
+        fpt, dwell, stats, idx, status = (t.cpu().numpy() for t in out)
+        assert np.array_equal(status, ref.status) and _same(fpt, ref.fpt) and _same(dwell, ref.dwell)
+        assert _same(stats, ref.stats) and np.array_equal(idx, ref.refine_idx)
+    assert (ref.status == 0).sum() > 100
+    eng.close()

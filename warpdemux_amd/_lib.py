@@ -41,7 +41,7 @@ EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
     "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_available", "wdx_comm_info", "wdx_comm_unique_id", "wdx_comm_init",
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait",
+    "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_refine_dev", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait",
     "wdx_host_alloc", "wdx_host_free", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
@@ -198,6 +198,8 @@ def load():
         L.wdx_fingerprint_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp]
         L.wdx_fingerprint_refine_batch.restype = C.c_int
         L.wdx_fingerprint_refine_batch.argtypes = [vp, vp, i64, i64, vp, vp, vp, P(SegParamsC), P(RefineParamsC), vp, vp, vp, vp, vp]
+        L.wdx_fingerprint_refine_dev.restype = C.c_int
+        L.wdx_fingerprint_refine_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), P(RefineParamsC), vp, vp, vp, vp, vp, vp]
         L.wdx_svm_set_model.restype = C.c_int
         L.wdx_svm_set_model.argtypes = [vp, P(SvmModelC)]
         L.wdx_svm_predict_dev.restype = C.c_int

@@ -534,6 +534,51 @@ int wdx_fingerprint_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_o
                               &t.main, (double *)ctx->fp_big.p);
 }
 
+int wdx_fingerprint_refine_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
+                               const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
+                               const int32_t *d_a_start, const int32_t *d_a_end, const uint8_t *d_ok,
+                               const wdx_seg_params *p_in, const wdx_refine_params *rp, double *d_fpt,
+                               int64_t *d_dwell, double *d_stats, int32_t *d_refine_idx, int32_t *d_status,
+                               void *stream) {
+    WDX_ENTER(ctx);
+    if (n_reads < 0 || !p_in || !rp || !rp->query ||
+        (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status || !d_refine_idx))) {
+        set_error("fingerprint_refine_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    if (rp->n_query < 1) {
+        set_error("consensus refinement: empty query");
+        return WDX_ERR_INVALID;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    wdx_seg_params pv = *p_in;
+    pv.barcode_num_events = rp->barcode_keep_events;  // K of the outputs
+    std::lock_guard<std::mutex> g(ctx->mu);
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = use_stream(ctx, s))) return rc;
+    if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
+    const size_t qb = ((size_t)rp->n_query * 8 + 15) / 16 * 16;
+    if ((rc = ctx->ref_buf.ensure(qb))) return rc;
+    const size_t wb = (size_t)fingerprint_refine_ws_bytes(n_reads);
+    if ((rc = ctx->ref_ws.ensure(wb ? wb : 8))) return rc;
+    // the consensus comes from the host (84 doubles): a pageable copy, staged by the runtime before the call returns
+    WDX_HIP_TRY(hipMemcpyAsync(ctx->ref_buf.p, rp->query, (size_t)rp->n_query * 8, hipMemcpyHostToDevice, s));
+    WDX_HIP_TRY(hipMemsetAsync(d_refine_idx, 0xff, (size_t)n_reads * 12, s));
+    WDX_HIP_TRY(hipMemsetAsync(ctx->ref_ws.p, 0, wb, s));
+    RefineDev *rf = nullptr;
+    struct RfGuard {
+        RefineDev *&r;
+        ~RfGuard() { free_refine_dev(r); }
+    } rf_guard{rf};
+    if ((rc = fill_refine_dev(*rp, (const double *)ctx->ref_buf.p, d_refine_idx, &rf))) return rc;
+    set_refine_ws(rf, ctx->ref_ws.p);
+    Timed t(ctx, WDX_K_FINGERPRINT, s);
+    return launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start, d_a_end, d_ok, pv, d_fpt,
+                              d_dwell, d_stats, d_status, s, ctx->fp_ws.p, ctx->knobs, &t.n_launches, nullptr, 0, 0, rf,
+                              nullptr, (double *)ctx->fp_big.p);
+}
+
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                                 int64_t stride, int64_t max_len, int64_t n_reads,
                                 const int32_t *d_a_start, const int32_t *d_a_end,

@@ -111,6 +111,24 @@ class DemuxEngine:
             self._stream()))
         return fpt, dwell, stats, status
 
+    def fingerprint_refine(self, sig, a_start, a_end, refine, *, offsets=None, stride=0, max_len: int, ok=None):
+        """Consensus-refinement branch on device-resident reads (wdx_fingerprint_refine_dev) ->
+        (fpt f64 (n,K), dwell i64 (n,K), stats f64 (n,6), refine_idx i32 (n,3), status i32), K = refine.barcode_keep_events."""
+        torch = self.torch
+        n = int(a_start.shape[0])
+        K = int(refine.barcode_keep_events)
+        fpt = torch.empty((n, K), dtype=torch.float64, device=self.tdev)
+        dwell = torch.empty((n, K), dtype=torch.int64, device=self.tdev)
+        stats = torch.empty((n, 6), dtype=torch.float64, device=self.tdev)
+        idx = torch.empty((n, 3), dtype=torch.int32, device=self.tdev)
+        status = torch.empty(n, dtype=torch.int32, device=self.tdev)
+        pc = self.params.to_c()
+        rc = refine.to_c()
+        _lib.check(self.L.wdx_fingerprint_refine_dev(
+            self.ctx.handle, _dp(sig), _dp(offsets), None, int(stride), int(max_len), n, _dp(a_start), _dp(a_end), _dp(ok),
+            C.byref(pc), C.byref(rc), _dp(fpt), _dp(dwell), _dp(stats), _dp(idx), _dp(status), self._stream()))
+        return fpt, dwell, stats, idx, status
+
     def dtw(self, X, want_argmin=True, out=None):
         """Device DTW of (n, L) float64 rows against the resident refs.  ``out=(dist, argmin)`` reuses the
         caller's device tensors (float32 (n, nY), int32 (n,) or None) instead of allocating."""
