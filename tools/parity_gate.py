@@ -8,7 +8,12 @@ sizes it names).  Run on the GPU box:  python tools/parity_gate.py [--r1 1000000
   r2        >= 1e5 fingerprints x 851 references x 25 points (WDX4's shape): float32 distances bitwise + argmin
   quantised 2e5 reads rounded to an ADC quantum (0.1755 pA) and to a coarse 2 pA grid: exact score ties and plateaus
             at scale through the fast kernel's plateau walk and its slow-path hand-over
-  long      5e4 reads with 6.4-8 k-sample windows (8192-sample instantiation) and 2e4 with 8.2-11.2 k (exact kernel)
+  long      5e4 reads with 6.4-8 k-sample windows (8192-sample instantiation), 2e4 with 8.2-11.2 k (exact kernel), 1e4 with
+            11.2-15.2 k (score curve in HBM)
+  triples   1e5 reads each on the RNA002 (110, 15, 30) and tRNA (120, 9, 18) triples (fast kernels of widths 30 / 18),
+            2.5e4 quantised reads on the RNA002 triple
+  refine    5e4 tRNA-like reads through the consensus-refinement flow (fast kernel + match kernel + tail kernel; long
+            barcode tails on the exact kernel): status, fingerprints, dwell, stats, query start / end, barcode start
 """
 import argparse
 import json
@@ -135,6 +140,67 @@ def main():
     out["long_6400_8000"] = gate_long(long_reads(6400, 8000, 8000), args.long)
     out["long_8200_11200"] = gate_long(long_reads(8200, 11200, 11200), args.long * 2 // 5)
     out["long_11201_15200"] = gate_long(long_reads(11201, 15200, 15200), args.long // 5)   # score curve in HBM
+    # ---- the other shipped parameter triples (fast kernels of widths 18 / 30) and the tRNA refinement flow -------------
+    def gate_triple(E, d, W, total, quant=None):
+        kw = dict(num_events=E, min_obs_per_base=d, running_stat_width=W, barcode_num_events=25)
+        ph_, po_ = sig_proc.SegParams(**kw), orc.SegParams(**kw)
+        bad = {"status": 0, "fpt": 0, "dwell": 0, "stats": 0}
+        for first in range(0, total, 16384):
+            n = min(16384, total - first)
+            mb, a_s, a_e, _ = synth.generate_minibatch(spec, 7_000_000 + first, n, 9000)
+            if quant:
+                mb = np.round(mb / np.float32(quant)).astype(np.float32) * np.float32(quant)
+            fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph_)
+            fpt, dwell, stats, status = oracle_fp(mb, a_s, a_e, po_, cores)
+            ok = status == 0
+            bad["status"] += int((fb.status != status).sum())
+            bad["fpt"] += int((fb.fpt[ok].view(np.uint64) != fpt[ok].view(np.uint64)).any(axis=1).sum())
+            bad["dwell"] += int((fb.dwell[ok] != dwell[ok]).any(axis=1).sum())
+            bad["stats"] += int((fb.stats[ok].view(np.uint64) != stats[ok].view(np.uint64)).any(axis=1).sum())
+        return {"reads": total, "mismatching_reads": bad, "ok": not any(bad.values())}
+    out["triple_rna002_110_15_30"] = gate_triple(110, 15, 30, args.quant // 2)
+    out["triple_trna_120_9_18"] = gate_triple(120, 9, 18, args.quant // 2)
+    out["triple_rna002_quantised"] = gate_triple(110, 15, 30, args.quant // 8, quant=0.1755)
+
+    def gate_refine(total):
+        cons = np.load(os.path.join(ROOT, "tests", "golden", "g8_refine.npz"))["consensus"]
+        kw = dict(min_obs_per_base=9, running_stat_width=18, num_events=120, barcode_num_events=25)
+        hp, hr = sig_proc.SegParams(**kw), sig_proc.RefineParams(query=cons, barcode_segm_events=25, barcode_keep_events=25)
+        op, orr = orc.SegParams(**kw), orc.RefineParams(query=cons, barcode_segm_events=25, barcode_keep_events=25)
+        bad = {"status": 0, "fpt": 0, "dwell": 0, "stats": 0, "idx": 0}
+        hist = np.zeros(8, dtype=np.int64)
+        for first in range(0, total, 4096):
+            n = min(4096, total - first)
+            r = np.random.default_rng(4000 + first)
+            rows = []
+            for i in range(n):
+                emb = r.random() > 0.1
+                lv = np.concatenate([r.normal(0, 1, int(r.integers(2, 34))), cons if emb else r.normal(0, 1, cons.size),
+                                     r.normal(0, 1, int(r.integers(26, 70)))]) * 12.0 + 85.0
+                dwl = r.integers(12, 60, lv.size)
+                rows.append((np.repeat(lv, dwl) + r.normal(0, r.uniform(0.8, 2.5), int(dwl.sum()))).astype(np.float32)[:8100])
+            stride = max(x.size for x in rows)
+            mb = np.full((n, stride), np.nan, dtype=np.float32)
+            for i, x in enumerate(rows):
+                mb[i, :x.size] = x
+            a_s = np.full(n, 100, dtype=np.int32)
+            a_e = np.array([x.size - 100 for x in rows], dtype=np.int32)
+            fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, hp, hr)
+            step = max(64, -(-n // (cores * 4)))
+            with ThreadPoolExecutor(cores) as ex:
+                parts = list(ex.map(lambda a: orc.fingerprint_refine_batch(mb[a:a + step], a_s[a:a + step], a_e[a:a + step], op, orr),
+                                    range(0, n, step)))
+            fpt, dwell, stats, idx, status = [np.concatenate([q[i] for q in parts]) for i in range(5)]
+            good, rep = status == 0, (status == 0) | (status == 6)
+            bad["status"] += int((fb.status != status).sum())
+            bad["fpt"] += int((fb.fpt[good].view(np.uint64) != fpt[good].view(np.uint64)).any(axis=1).sum())
+            bad["dwell"] += int((fb.dwell[good] != dwell[good]).any(axis=1).sum())
+            bad["stats"] += int((fb.stats[rep].view(np.uint64) != stats[rep].view(np.uint64)).any(axis=1).sum())
+            bad["idx"] += int((fb.refine_idx[rep] != idx[rep]).any(axis=1).sum())
+            hist += np.bincount(status, minlength=8)[:8]
+        return {"reads": total, "mismatching_reads": bad, "status_histogram": hist.tolist(), "ok": not any(bad.values())}
+    out["trna_refinement_flow"] = gate_refine(args.quant // 4)
+
     out["all_ok"] = bool(out["r1"]["parity"]["ok"] and out["r2"]["bitwise_equal"] and out["r2"]["argmin_equal"]
                          and all(v["ok"] for k, v in out.items() if isinstance(v, dict) and "ok" in v))
     print(json.dumps(out, indent=1))
