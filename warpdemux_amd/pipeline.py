@@ -104,14 +104,26 @@ class MinibatchPipeline:
     def run(self, minibatches):
         """Drive an iterable of (signals, adapter_start, adapter_end[, success]) through both slots; yields one
         DemuxBatch per minibatch, in order.  The iterable is advanced (= the caller's fill runs) while the previous
-        minibatch is in flight."""
+        minibatch is in flight.
+
+        Order per minibatch k: wait(k - 2), THEN next(iterable), then submit(k) -- so a generator that refills two
+        rotating page-locked buffers never writes into a buffer whose submit has not been waited
+        for (submit()'s contract, wdx.h: inputs stay untouched until the matching wait); minibatch k - 1 is still in
+        flight while the generator fills buffer k."""
+        it = iter(minibatches)
         pending = []
-        for k, mb in enumerate(minibatches):
+        k = 0
+        while True:
             slot = k % self.N_SLOTS
-            if len(pending) == self.N_SLOTS:
+            if len(pending) == self.N_SLOTS:   # the slot (and the caller's buffer) about to be reused
                 yield self.wait(pending.pop(0))
+            try:
+                mb = next(it)
+            except StopIteration:
+                break
             self.submit(slot, *mb)
             pending.append(slot)
+            k += 1
         for slot in pending:
             yield self.wait(slot)
 
