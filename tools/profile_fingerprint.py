@@ -70,6 +70,18 @@ if fast:
         prev = np.where(okm, cur, prev)
     print("    small-list size median %d p99 %d" % (np.median(q[:, 6]), np.percentile(q[:, 6], 99)))
 
+if fast and (p[:, 26] != 0).any():
+    c = p[p[:, 24] != 0]
+    order = [26, 27, 28, 29, 30, 31, 23, 24]
+    lab = ["load + extremes", "median: zero + histogram", "median: find the bin", "median: gather + rank (+ even n)",
+           "keys of |x - med|", "MAD: zero + histogram", "MAD: find bin + gather + rank"]
+    print("  clip_bounds_kernel, one wave per read (100 MHz ticks: x24 = shader cycles at 2.4 GHz; median / mean over %d reads):" % len(c))
+    for i, name in enumerate(lab):
+        dd = c[:, order[i + 1]] - c[:, order[i]]
+        print(f"    {name:34s} {np.median(dd):8.0f} {dd.mean():9.1f}")
+    tt = c[:, 24] - c[:, 26]
+    print(f"    {'total':34s} {np.median(tt):8.0f} {tt.mean():9.1f}")
+
 if fast and len(sys.argv) > 3:
     # ablation: throughput of the kernel cut after phase k (no stamps: prof_reads = 0), steady state
     nbig = int(sys.argv[3])

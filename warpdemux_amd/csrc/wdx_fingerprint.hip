@@ -22,9 +22,14 @@
 //   P6 event means     sequential float64 sums per segment (A5)
 //   P7 normalise+stats numpy pairwise mean/std, medians by rank counting, tail-K extract (A6)
 #include "wdx_common.h"
+#include "wdx_fp_types.h"
+#include "wdx_wave.h"
 
 #include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 namespace wdx {
 
@@ -43,59 +48,6 @@ static_assert(kBigCap % 64 == 0 && kBigCap >= 15200, "the exact path must take e
 
 enum : unsigned char { ST_NONE = 0, ST_UNDECIDED = 1, ST_KEPT = 2, ST_DROPPED = 3, ST_SELECTED = 4 };
 
-// consensus-guided refinement (sig_proc.py:257-378, 452-521); query == nullptr: plain branch
-struct RefineDev {
-    const double *query;   // consensus signal, DEVICE pointer
-    int nq, norm;          // its length; consensus_subseq_match_normalization (WDX_NORM_*)
-    double pen;            // consensus_subseq_match_penalty (un-squared)
-    int psi1b, psi2b;      // relaxations at the beginning of the query / of the series
-    int ub_start, lb_end, ub_end;
-    int E2;                // barcode_num_events[0]
-    int32_t *idx;          // (n_reads, 3) seg_cons_query_start, seg_cons_query_end, sig_barcode_start; nullable
-    unsigned char *ws;     // n_reads RefineRec (device): the fast kernels' hand-over to fingerprint_refine_tail_kernel;
-                           // null -> the refinement branch runs on the exact kernel only
-};
-// What a fast kernel leaves behind for a read of the refinement branch: the adapter's segmentation (bit-identical to
-// the exact kernel's) and the clip bounds, so that the tail kernel can re-create the clipped samples of the barcode.
-struct RefineRec {
-    int32_t state;         // 0 untouched, 1 segmented by a fast kernel, 3 matched (fingerprint_refine_match_kernel),
-                           // 4 reported by the match kernel, 2 handed on to the exact kernel (tail beyond kTailCap)
-    int32_t n;             // adapter window length
-    float lo, hi;          // clip bounds
-    int32_t cpts[132];     // nseg + 1 boundaries (nseg <= 128)
-    double ev[128];        // nseg event means
-    double m[8];           // RefineMatch of the match kernel (bit copy)
-};
-static_assert(sizeof(RefineRec) == 1632, "fingerprint_refine_ws_bytes");
-constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
-constexpr int kRefineMaxSeries = 128;
-
-struct FpArgs {
-    const float *sig;
-    const int64_t *row_off;
-    const int32_t *row_len;
-    int64_t stride;
-    int64_t n_reads;
-    const int32_t *a_start;
-    const int32_t *a_end;
-    const uint8_t *ok;
-    wdx_seg_params p;
-    double *fpt;
-    int64_t *dwell;
-    double *stats;
-    int32_t *status;
-    int cap;             // LDS capacity in samples
-    int64_t block_base;  // first read of this launch (grid.x * block.x must stay below 2^32)
-    long long *prof;     // diagnostic build only: 32 int64 per read (cycle stamps etc.)
-    int64_t prof_reads;
-    int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
-    int exact_scores;    // fast kernel: exact t-scores from the first attempt (WDX_OPT_FAST_EXACT_SCORES)
-    RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
-    double *big_scores;  // kBigSlots x kBigCap doubles: score curves of windows beyond the LDS capacity (nullable)
-    int defer_big;       // 1: a window beyond `cap` is left to fingerprint_big_kernel (no status written here)
-    int no_list;         // WDX_OPT_EXACT_NO_PEAK_LIST: fp_segment in position space only (diagnostic)
-};
-
 struct alignas(8) FpShared {
     unsigned long long red64[16];
     unsigned red_a[16], red_b[16], red_c[16];
@@ -108,30 +60,7 @@ struct alignas(8) FpShared {
     double stat[6];
 };
 
-// med -/+ thresh*mad of the outlier clip (sig_proc.py:426-431): in float32 (NumPy >= 2 with a Python-float
-// threshold) or in float64 from the double threshold, rounded to float32 once (NumPy 1.x, np.float64 threshold)
-__device__ __forceinline__ void clip_bounds(const wdx_seg_params &P, float med, float mad, float &lo, float &hi) {
-    if (P.clip_bounds_f64) {
-        const double tm = P.outlier_thresh_f64 * (double)mad;
-        lo = (float)((double)med - tm);
-        hi = (float)((double)med + tm);
-    } else {
-        const float tm = P.outlier_thresh * mad;
-        lo = med - tm;
-        hi = med + tm;
-    }
-}
-
 // ---- block primitives ----------------------------------------------------------------------------
-
-__device__ __forceinline__ unsigned f32_key(float x) {
-    unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(unsigned k) {
-    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
 
 template <int BLOCK>
 __device__ __forceinline__ void block_minmax_count(unsigned kmin, unsigned kmax, unsigned cnt,
@@ -1529,6 +1458,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
     });
 }
 
+#ifndef WDX_DEV_KERNELS_ONLY  // (development: a TU that instantiates single kernels includes this file with the macro set)
 static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list, hipStream_t stream) {
     static LdsAttr attr_m, attr_t;
     const size_t lds_m = refine_match_lds_bytes(), lds_t = refine_tail_lds_bytes();
@@ -1547,7 +1477,9 @@ static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list
 }
 int64_t fingerprint_refine_ws_bytes(int64_t n_reads) { return (int64_t)sizeof(RefineRec) * (n_reads > 0 ? n_reads : 0); }
 
+#endif  // WDX_DEV_KERNELS_ONLY
 #include "wdx_fingerprint_fast.inc"
+#ifndef WDX_DEV_KERNELS_ONLY
 
 static size_t fp_lds_bytes(int cap) {
     size_t b = 0;
@@ -1644,8 +1576,8 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
     return WDX_SUCCESS;
 }
 
-// four counters + four read lists (slow, big0, big1, retry: see launch_fingerprint)
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 16 * (n_reads > 0 ? n_reads : 0); }
+// four counters + four read lists (slow, big0, big1, retry: see launch_fingerprint) + one ClipRec per read
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 32 * (n_reads > 0 ? n_reads : 0); }
 
 // The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
@@ -1768,8 +1700,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool with_big0 = chain && capF == 5120;            // windows of 5121..6144 samples, peak-list overflows
         const bool with_big1 = chain && capF >= 5120 && cap > 6144;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
+        ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 16 + 16 * n_reads);
         FastArgs F{A, capF, capP, count, list, nullptr, nullptr, nullptr, nullptr, 0u, approx ? count + 3 : nullptr,
-                   approx ? retry : nullptr};
+                   approx ? retry : nullptr, nullptr};
         if (with_big0) {
             F.big_count = count + 1;
             F.big_list = big0;
@@ -1777,31 +1710,41 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             F.big_count = count + 2;
             F.big_list = big1;
         }
+        // Large batches: the clip bounds of the MAIN kernel's reads are computed ahead of it by clip_bounds_kernel (one wave
+        // per read, wdx_clip.hip) and the main kernel starts at the clip (EXT instantiation).  The list kernels behind it
+        // (a tenth of the reads, longer windows) and small batches (live ticks: every launch counts) keep the in-kernel
+        // radix selects.
+        const bool ext = large_batch || capF == 5120;
+        F.clip = ext ? clip : nullptr;
         void (*kern)(FastArgs) = nullptr;
         void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
         void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
         int slot = 0;
         if (combo == 2) {
-            kern = capF == 5120 ? fingerprint_fast_kernel<kNptMid, false, 18, 1> : fingerprint_fast_kernel<kNptLarge, false, 18, 1>;
+            kern = capF == 5120 ? fingerprint_fast_kernel<kNptMid, false, 18, 1, true>
+                                : (ext ? fingerprint_fast_kernel<kNptLarge, false, 18, 1, true>
+                                       : fingerprint_fast_kernel<kNptLarge, false, 18, 1, false>);
             kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 18, 1>;
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, 18, 1>;
             slot = capF == 5120 ? 1 : 2;
         } else if (combo == 3) {
-            kern = fingerprint_fast_kernel<kNptLarge, false, 30, 2>;
+            kern = ext ? fingerprint_fast_kernel<kNptLarge, false, 30, 2, true> : fingerprint_fast_kernel<kNptLarge, false, 30, 2, false>;
             kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 30, 2>;
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, 30, 2>;
             slot = 2;
         } else if (capF == 4096) {
-            kern = d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>;
+            kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptSmall, true, kFW, 1, true> : fingerprint_fast_kernel<kNptSmall, false, kFW, 1, true>)
+                       : (d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>);
         } else if (capF == 5120) {
-            kern = d_prof ? fingerprint_fast_kernel<kNptMid, true> : fingerprint_fast_kernel<kNptMid, false>;
+            kern = d_prof ? fingerprint_fast_kernel<kNptMid, true, kFW, 1, true> : fingerprint_fast_kernel<kNptMid, false, kFW, 1, true>;
             slot = 1;
         } else {
-            kern = d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>;
+            kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptLarge, true, kFW, 1, true> : fingerprint_fast_kernel<kNptLarge, false, kFW, 1, true>)
+                       : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
             slot = 2;
         }
-        static LdsAttr attr_fast[3][6];
-        if (int rc = attr_fast[combo - 1][(d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
+        static LdsAttr attr_fast[3][12];
+        if (int rc = attr_fast[combo - 1][(ext ? 6 : 0) + (d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, FB, flds);
@@ -1820,6 +1763,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                 if (counted && n_launches) ++*n_launches;
             }
         };
+        if (ext) {
+            // A1 for the main kernel's reads (windows of 256 .. capF samples; longer ones are flagged CLIP_NONE and the
+            // main kernel hands them to the lists before it would look at their record)
+            if (int rc = launch_clip_bounds(A, clip, capF, stream)) return rc;
+        }
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         launch_sliced(kern, F, n_reads, flds, true);
         if (main_ev && main_ev->first) {
@@ -1840,17 +1788,17 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
             const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
             FastArgs F1{A, capF1, capP1, count, list, with_big1 ? count + 2 : nullptr, with_big1 ? big1 : nullptr,
-                        count + 1, big0, 0u, F.retry_count, F.retry_list};
+                        count + 1, big0, 0u, F.retry_count, F.retry_list, nullptr};
             launch_sliced(kern_l1, F1, g1, flds1, false);
             if (g1 < n_reads) {
                 FastArgs F1b{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big0, (unsigned)g1, F.retry_count,
-                             F.retry_list};
+                             F.retry_list, nullptr};
                 hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
                                    stream, F1b);
             }
         }
         if (with_big1) {
-            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list};
+            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list, nullptr};
             hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2, stream,
                                F2);
         }
@@ -1858,12 +1806,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // about 2 reads in 1000: a grid for 1/64 of the batch on the 6144-sample instantiation with exact scores
             // (a window beyond 6144 samples moves on to the slow path), the striding kernel beyond
             const int64_t g3 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 64));
-            FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr};
+            FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr, nullptr};
             F3.a.exact_scores = 1;
             launch_sliced(kern_l1, F3, g3, flds1, false);
             if (g3 < n_reads) {
                 FastArgs F3b{F3.a, capF2, capP2, count, list, nullptr, nullptr, count + 3, retry, (unsigned)g3, nullptr,
-                             nullptr};
+                             nullptr, nullptr};
                 hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
                                    stream, F3b);
             }
@@ -1883,6 +1831,14 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             WDX_HIP_TRY(hipStreamSynchronize(stream));
             fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u beyond 6144 samples, %u redone with "
                             "exact scores, %u on the exact general kernel\n", (long long)n_reads, c[1], c[2], c[3], c[0]);
+            if (ext) {
+                std::vector<ClipRec> h((size_t)n_reads);
+                WDX_HIP_TRY(hipMemcpy(h.data(), clip, sizeof(ClipRec) * (size_t)n_reads, hipMemcpyDeviceToHost));
+                long long f[4] = {0, 0, 0, 0};
+                for (const ClipRec &cr : h) ++f[cr.flag & 3];
+                fprintf(stderr, "[wdx] clip_bounds_kernel flags: %lld not taken, %lld ok, %lld NaN / negative, %lld sums not "
+                                "provably exact\n", f[0], f[1], f[2], f[3]);
+            }
         }
         return WDX_SUCCESS;
     }
@@ -1892,5 +1848,6 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     if (with_huge) return launch_fp_big(A, cap, nullptr, nullptr, stream);
     return WDX_SUCCESS;
 }
+#endif  // WDX_DEV_KERNELS_ONLY
 
 }  // namespace wdx

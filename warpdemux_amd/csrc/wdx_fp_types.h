@@ -1,0 +1,102 @@
+// Device-side argument blocks of the fingerprint kernels, shared by wdx_fingerprint.hip (the exact general kernel, the
+// fast kernels' launch chain) and wdx_clip.hip (clip_bounds_kernel).  Internal.
+#pragma once
+#include "wdx_common.h"
+
+namespace wdx {
+
+constexpr int kHBits = 11;       // radix digit of the float32 medians (2048-bin histogram)
+constexpr int kHB = 1 << kHBits; // histogram bins
+
+// consensus-guided refinement (sig_proc.py:257-378, 452-521); query == nullptr: plain branch
+struct RefineDev {
+    const double *query;   // consensus signal, DEVICE pointer
+    int nq, norm;          // its length; consensus_subseq_match_normalization (WDX_NORM_*)
+    double pen;            // consensus_subseq_match_penalty (un-squared)
+    int psi1b, psi2b;      // relaxations at the beginning of the query / of the series
+    int ub_start, lb_end, ub_end;
+    int E2;                // barcode_num_events[0]
+    int32_t *idx;          // (n_reads, 3) seg_cons_query_start, seg_cons_query_end, sig_barcode_start; nullable
+    unsigned char *ws;     // n_reads RefineRec (device): the fast kernels' hand-over to fingerprint_refine_tail_kernel;
+                           // null -> the refinement branch runs on the exact kernel only
+};
+// What a fast kernel leaves behind for a read of the refinement branch: the adapter's segmentation (bit-identical to
+// the exact kernel's) and the clip bounds, so that the tail kernel can re-create the clipped samples of the barcode.
+struct RefineRec {
+    int32_t state;         // 0 untouched, 1 segmented by a fast kernel, 3 matched (fingerprint_refine_match_kernel),
+                           // 4 reported by the match kernel, 2 handed on to the exact kernel (tail beyond kTailCap)
+    int32_t n;             // adapter window length
+    float lo, hi;          // clip bounds
+    int32_t cpts[132];     // nseg + 1 boundaries (nseg <= 128)
+    double ev[128];        // nseg event means
+    double m[8];           // RefineMatch of the match kernel (bit copy)
+};
+static_assert(sizeof(RefineRec) == 1632, "fingerprint_refine_ws_bytes");
+constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
+constexpr int kRefineMaxSeries = 128;
+
+struct FpArgs {
+    const float *sig;
+    const int64_t *row_off;
+    const int32_t *row_len;
+    int64_t stride;
+    int64_t n_reads;
+    const int32_t *a_start;
+    const int32_t *a_end;
+    const uint8_t *ok;
+    wdx_seg_params p;
+    double *fpt;
+    int64_t *dwell;
+    double *stats;
+    int32_t *status;
+    int cap;             // LDS capacity in samples
+    int64_t block_base;  // first read of this launch (grid.x * block.x must stay below 2^32)
+    long long *prof;     // diagnostic build only: 32 int64 per read (cycle stamps etc.)
+    int64_t prof_reads;
+    int stop_phase;      // diagnostic build only: leave the fast kernel after this phase (0 = run all)
+    int exact_scores;    // fast kernel: exact t-scores from the first attempt (WDX_OPT_FAST_EXACT_SCORES)
+    RefineDev rf;        // rf.query != nullptr: consensus-refinement branch (exact kernel only)
+    double *big_scores;  // kBigSlots x kBigCap doubles: score curves of windows beyond the LDS capacity (nullable)
+    int defer_big;       // 1: a window beyond `cap` is left to fingerprint_big_kernel (no status written here)
+    int no_list;         // WDX_OPT_EXACT_NO_PEAK_LIST: fp_segment in position space only (diagnostic)
+};
+
+// Clip bounds of one read, computed ahead of the fast kernels' launch chain by clip_bounds_kernel (one wave per read,
+// wdx_fingerprint_clip.inc).  flag: CLIP_NONE = not computed (failed detection, window outside the kernel's range),
+// CLIP_OK = bounds valid and every partial sum of the clipped samples exactly representable, CLIP_NAN_NEG = a
+// negative sample / -0.0 / infinity / NaN in the window, CLIP_INEXACT = the exactness gate fails.
+struct alignas(16) ClipRec {
+    float lo, hi;   // med -/+ thresh * mad (float32, clip_bounds)
+    float cmax;     // largest clipped sample (-> the variance floor of the approximate score keys)
+    int32_t flag;
+};
+enum : int32_t { CLIP_NONE = 0, CLIP_OK = 1, CLIP_NAN_NEG = 2, CLIP_INEXACT = 3 };
+
+// med -/+ thresh*mad of the outlier clip (sig_proc.py:426-431): in float32 (NumPy >= 2 with a Python-float
+// threshold) or in float64 from the double threshold, rounded to float32 once (NumPy 1.x, np.float64 threshold)
+__device__ __forceinline__ void clip_bounds(const wdx_seg_params &P, float med, float mad, float &lo, float &hi) {
+    if (P.clip_bounds_f64) {
+        const double tm = P.outlier_thresh_f64 * (double)mad;
+        lo = (float)((double)med - tm);
+        hi = (float)((double)med + tm);
+    } else {
+        const float tm = P.outlier_thresh * mad;
+        lo = med - tm;
+        hi = med + tm;
+    }
+}
+
+__device__ __forceinline__ unsigned f32_key(float x) {
+    unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// A1 for a whole batch ahead of the fast kernels' launch chain (wdx_clip.hip): one ClipRec per read of A; windows of
+// 256 .. cap samples (cap = 4096, 5120 or 6144: the main fast instantiation's) are taken, the others are flagged CLIP_NONE.
+int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t stream);
+
+}  // namespace wdx
