@@ -362,6 +362,15 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
 int wdx_selftest_score_dev(wdx_ctx *ctx, const double *d_dm, const double *d_vs, int64_t n, double *d_fast,
                            double *d_ref, void *stream);
 
+/* Self-test of clip_bounds_kernel (A1 ahead of the fast fingerprint kernels: one wave per read): packed
+ * reads (d_row_off int64[n_reads+1]) or rows of `stride` samples; cap = 4096, 5120 or 6144 selects the instantiation
+ * (windows of 256..cap samples are taken).  d_rec: n_reads records of 16 bytes {float lo, hi, cmax; int32 flag}
+ * (flag 0 not taken, 1 bounds valid + sums provably exact, 2 NaN / infinity / no non-negative sample, 3 exactness gate
+ * fails or the negative-sample shortcut does not apply).  Must equal sig_proc.py:421-431's med -/+ thresh * mad bit for bit. */
+int wdx_selftest_clip_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off, int64_t stride, int64_t n_reads,
+                          const int32_t *d_a_start, const int32_t *d_a_end, const wdx_seg_params *p, int32_t cap,
+                          void *d_rec, void *stream);
+
 /* Diagnostic: stream n floats with coalesced dword loads (known byte count) to calibrate the
  * FETCH_SIZE PMC counter for the fingerprint kernel's access pattern. */
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream);

@@ -45,7 +45,7 @@ EXPORTS = [
     "wdx_host_alloc", "wdx_host_free", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
-    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev",
+    "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
 ]
 
 
@@ -234,6 +234,8 @@ def load():
         L.wdx_fingerprint_profile_dev.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, P(SegParamsC), vp, vp, i64, i32, i32, vp]
         L.wdx_selftest_score_dev.restype = C.c_int
         L.wdx_selftest_score_dev.argtypes = [vp, vp, vp, i64, vp, vp, vp]
+        L.wdx_selftest_clip_dev.restype = C.c_int
+        L.wdx_selftest_clip_dev.argtypes = [vp, vp, vp, i64, i64, vp, vp, P(SegParamsC), i32, vp, vp]
         L.wdx_calib_read_dev.restype = C.c_int
         L.wdx_calib_read_dev.argtypes = [vp, vp, i64, vp, vp]
         L.wdx_synth_lengths_dev.restype = C.c_int

@@ -1244,6 +1244,20 @@ int wdx_selftest_score_dev(wdx_ctx *ctx, const double *d_dm, const double *d_vs,
     return launch_score_selftest(d_dm, d_vs, n, d_fast, d_ref, (hipStream_t)stream);
 }
 
+int wdx_selftest_clip_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off, int64_t stride, int64_t n_reads,
+                          const int32_t *d_a_start, const int32_t *d_a_end, const wdx_seg_params *p, int32_t cap,
+                          void *d_rec, void *stream) {
+    WDX_ENTER(ctx);
+    if (n_reads < 0 || !p || (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_rec)) ||
+        (cap != 4096 && cap != 5120 && cap != 6144)) {
+        set_error("selftest_clip_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    return launch_clip_bounds_selftest(d_sig, d_row_off, stride, n_reads, d_a_start, d_a_end, *p, cap, d_rec,
+                                       (hipStream_t)stream);
+}
+
 int wdx_calib_read_dev(wdx_ctx *ctx, const float *d_p, int64_t n, float *d_out, void *stream) {
     WDX_ENTER(ctx);
     return launch_calib_read(d_p, n, d_out, (hipStream_t)stream);

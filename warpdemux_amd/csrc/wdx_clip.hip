@@ -516,4 +516,18 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
     return WDX_SUCCESS;
 }
 
+int launch_clip_bounds_selftest(const float *d_sig, const int64_t *d_row_off, int64_t stride, int64_t n_reads,
+                                const int32_t *d_a_start, const int32_t *d_a_end, const wdx_seg_params &p, int cap,
+                                void *d_rec, hipStream_t stream) {
+    FpArgs A{};
+    A.sig = d_sig;
+    A.row_off = d_row_off;
+    A.stride = stride;
+    A.n_reads = n_reads;
+    A.a_start = d_a_start;
+    A.a_end = d_a_end;
+    A.p = p;
+    return launch_clip_bounds(A, reinterpret_cast<ClipRec *>(d_rec), cap, stream);
+}
+
 }  // namespace wdx

@@ -123,6 +123,9 @@ int64_t fingerprint_refine_ws_bytes(int64_t n_reads);
 void set_refine_ws(struct RefineDev *rf, void *d_ws);
 // device bytes the exact kernel needs for the score curves of windows beyond its LDS capacity (0 when max_len fits)
 int64_t fingerprint_big_bytes(int64_t max_len);
+int launch_clip_bounds_selftest(const float *d_sig, const int64_t *d_row_off, int64_t stride, int64_t n_reads,
+                                const int32_t *d_a_start, const int32_t *d_a_end, const wdx_seg_params &p, int cap,
+                                void *d_rec, hipStream_t stream);
 int launch_score_selftest(const double *dm, const double *vs, int64_t n, double *fast, double *ref, hipStream_t stream);
 
 // ---- synthetic generator (wdx_synth.hip) -------------------------------------------------------
