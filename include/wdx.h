@@ -338,6 +338,7 @@ int wdx_reduce_counts_host(wdx_ctx *ctx, int64_t *counts, int32_t n);
 #define WDX_K_SVM 4
 #define WDX_K_REDUCE 5
 #define WDX_K_FINGERPRINT_MAIN 6 /* the main fast fingerprint kernel alone (WDX_K_FINGERPRINT = the whole chain) */
+#define WDX_K_FINGERPRINT_CLIP 7 /* clip_bounds_kernel alone (median / MAD / clip bounds ahead of the main kernel) */
 /* When enabled, every kernel launch through this context is bracketed by hipEvents on its
  * stream; wdx_kernel_time() synchronises them and returns accumulated ms and launch count. */
 int wdx_kernel_timing(wdx_ctx *ctx, int enable);

@@ -170,3 +170,82 @@ def test_single_process_helpers_are_noops():
     dist.barrier()
     assert dist.env_rank_world() == (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
                                      int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def _worker8(rank, world, port, n_total, out_q):
+    """C4's shape on CPU: world 8, one global read range, synthetic reads by GLOBAL index."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", OMP_NUM_THREADS="1")
+    import torch
+
+    torch.set_num_threads(1)
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import dist, synth
+
+    dist.init_process_group("gloo")
+    lo, hi = dist.shard_range(n_total, rank, world)
+    spec = synth.SynthSpec(n_barcodes=10)
+    K = 25
+    refs = np.random.default_rng(0).normal(size=(10, K))
+    call = np.zeros(0, dtype=np.int64)
+    if hi > lo:
+        sig, off, a_s, a_e, bc = synth.generate_packed(spec, lo, hi - lo)
+        fpt, dwell, stats, status = orc.fingerprint_packed(sig, off, a_s, a_e, orc.SegParams(barcode_num_events=K))
+        ok = status == 0
+        call = np.full(hi - lo, 10, dtype=np.int64)
+        call[ok] = orc.argmin_rows(orc.dtw_matrix(fpt[ok], refs, 15, 0.1))
+    counts = torch.from_numpy(np.bincount(call, minlength=11).astype(np.int64))
+    red = dist.CountReducer(None)
+    red(counts)
+    per_rank = dist.gather_over_ranks(float(10 * rank + 1))
+    out_q.put((rank, lo, hi, counts.numpy(), per_rank, dist.max_over_ranks(float(rank))))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_shards_tile_the_global_range_and_the_histogram_is_the_single_process_one():
+    """BASELINE config 4's layout (8 ranks, contiguous shards of ONE global read range, one int64[11] sum) on CPU:
+    the shards tile [0, n) in rank order -- including a total that leaves the last rank short -- every rank ends with
+    the same histogram, it sums to n, and it equals the histogram of the same reads in one process; per-rank timings
+    come back in rank order (bench.py's per_rank_ms_per_step)."""
+    import torch.multiprocessing as mp
+
+    from warpdemux_amd import dist as wdist
+
+    world, n_total = 8, 8 * 6 - 5          # ceil(43 / 8) = 6: ranks 0..6 take 6 reads, rank 7 takes 1
+    for total in (0, 1, 7, 8, 9, 43, 40_000_000):
+        cover = [wdist.shard_range(total, r, world) for r in range(world)]
+        assert cover[0][0] == 0 and cover[-1][1] == total
+        assert all(cover[r][1] == cover[r + 1][0] for r in range(world - 1))
+        assert all(0 <= hi - lo <= -(-total // world) for lo, hi in cover)
+    assert [hi - lo for lo, hi in (wdist.shard_range(40_000_000, r, 8) for r in range(8))] == [5_000_000] * 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(lo, hi) for _, lo, hi, _, _, _ in res] == [wdist.shard_range(n_total, r, world) for r in range(world)]
+    g = res[0][3]
+    assert all(np.array_equal(g, c) for _, _, _, c, _, _ in res) and g.sum() == n_total
+    assert all(pr == [float(10 * r + 1) for r in range(world)] for _, _, _, _, pr, _ in res)
+    assert all(mx == float(world - 1) for *_, mx in res)
+
+    sys.path.insert(0, ROOT)
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import synth
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K = 25
+    refs = np.random.default_rng(0).normal(size=(10, K))
+    sig, off, a_s, a_e, bc = synth.generate_packed(spec, 0, n_total)
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig, off, a_s, a_e, orc.SegParams(barcode_num_events=K))
+    ok = status == 0
+    call = np.full(n_total, 10, dtype=np.int64)
+    call[ok] = orc.argmin_rows(orc.dtw_matrix(fpt[ok], refs, 15, 0.1))
+    assert np.array_equal(g, np.bincount(call, minlength=11))

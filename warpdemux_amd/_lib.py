@@ -23,7 +23,7 @@ WDX_ERR_HIP = -3
 WDX_ERR_UNSUPPORTED = -4
 WDX_ERR_NO_REFS = -5
 
-K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE, K_FINGERPRINT_MAIN = 0, 1, 2, 3, 4, 5, 6
+K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE, K_FINGERPRINT_MAIN, K_FINGERPRINT_CLIP = 0, 1, 2, 3, 4, 5, 6, 7
 
 # wdx_ctx_set_option selectors (diagnostics; the product path leaves all of them 0)
 OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBUG_OCCUPANCY, OPT_FAST_PEAK_CAP = 1, 2, 3, 4, 5, 6

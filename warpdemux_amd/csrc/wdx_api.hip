@@ -124,6 +124,15 @@ Timed::Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
         }
         main.first = m.first;
         main.second = m.second;
+        std::pair<hipEvent_t, hipEvent_t> q{nullptr, nullptr};
+        if (!c->pool.empty()) {
+            q = c->pool.back();
+            c->pool.pop_back();
+        } else if (hipEventCreate(&q.first) != hipSuccess || hipEventCreate(&q.second) != hipSuccess) {
+            q = {nullptr, nullptr};
+        }
+        main.c_first = q.first;
+        main.c_second = q.second;
     }
 }
 
@@ -138,6 +147,14 @@ Timed::~Timed() {
             c->pending_launches[WDX_K_FINGERPRINT_MAIN].push_back(n_launches > 0 ? n_launches : 1);
         } else {
             c->pool.push_back({main.first, main.second});
+        }
+    }
+    if (main.c_first) {
+        if (main.c_recorded) {
+            c->pending[WDX_K_FINGERPRINT_CLIP].push_back({main.c_first, main.c_second});
+            c->pending_launches[WDX_K_FINGERPRINT_CLIP].push_back(1);
+        } else {
+            c->pool.push_back({main.c_first, main.c_second});
         }
     }
 }

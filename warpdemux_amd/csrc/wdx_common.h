@@ -107,6 +107,9 @@ void free_refine_dev(struct RefineDev *rf);
 struct MainEvents {
     hipEvent_t first = nullptr, second = nullptr;
     bool recorded = false;
+    // a third pair around clip_bounds_kernel (WDX_K_FINGERPRINT_CLIP): the launch ahead of the main kernel
+    hipEvent_t c_first = nullptr, c_second = nullptr;
+    bool c_recorded = false;
 };
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,

@@ -1766,7 +1766,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (ext) {
             // A1 for the main kernel's reads (windows of 256 .. capF samples; longer ones are flagged CLIP_NONE and the
             // main kernel hands them to the lists before it would look at their record)
+            if (main_ev && main_ev->c_first) (void)hipEventRecord(main_ev->c_first, stream);
             if (int rc = launch_clip_bounds(A, clip, capF, stream)) return rc;
+            if (main_ev && main_ev->c_first) {
+                (void)hipEventRecord(main_ev->c_second, stream);
+                main_ev->c_recorded = true;
+            }
         }
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         launch_sliced(kern, F, n_reads, flds, true);

@@ -195,3 +195,17 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, device=None):
+    """All ranks' host scalars, in rank order (per-rank timing: which rank was the straggler)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros(world, dtype=torch.float64, device=device if device is not None else "cpu")
+    t[rank] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu().tolist()]
