@@ -38,6 +38,8 @@ struct ClipArgs {
     FpArgs a;
     ClipRec *rec;
     int cap;  // windows of 256 .. cap samples are taken (cap <= 64 * NPL)
+    const unsigned *in_count;  // list form: the first `grid` entries of a device-side read list (else null)
+    const int32_t *in_list;
 };
 
 // xor-exchange inside a row of 16 / a quad (VALU only)
@@ -178,10 +180,14 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     // every element of the groups that hold data, highest group first: ONE dispatch on ng (a compare tree) and then
     // straight fall-through, instead of a test per group and pass
     // every group that holds data (a uniform test per group; a switch on ng with fall-through was no faster)
+    // (an opaque copy of ng per pass: the group tests are one scalar compare each -- as common subexpressions of all
+    // passes the compiler keeps 20 lane masks alive for the whole kernel and spills them through v_writelane / v_readlane)
     auto each4 = [&](auto &&f4) __attribute__((always_inline)) {
+        int ngp = ng;
+        asm volatile("" : "+s"(ngp));
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
-            if (j < ng) f4(u[4 * j], u[4 * j + 1], u[4 * j + 2], u[4 * j + 3]);
+            if (j < ngp) f4(u[4 * j], u[4 * j + 1], u[4 * j + 2], u[4 * j + 3]);
         }
     };
     auto each = [&](auto &&f) __attribute__((always_inline)) {
@@ -500,13 +506,40 @@ __global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bound
     clip_wave<NPL>(C.a, C.rec, r, C.cap, clip_lds[wave]);
 }
 
+// the reads of a device-side list (the main kernel's hand-overs to the 6144-sample list kernel): one wave per entry,
+// waves past the end of the list and reads that already have their record leave at once
+template <int NPL>
+__global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bounds_list_kernel(ClipArgs C) {
+    __shared__ __attribute__((aligned(16))) unsigned clip_lds[kClipWaves][kClipWaveWords];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t k = C.a.block_base + (int64_t)blockIdx.x * kClipWaves + wave;
+    if (k >= (int64_t)*C.in_count) return;
+    const int64_t r = C.in_list[k];
+    if (C.rec[r].flag != CLIP_NONE) return;
+    clip_wave<NPL>(C.a, C.rec, r, C.cap, clip_lds[wave]);
+}
+
+int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
+                            hipStream_t stream) {
+    if (n_entries <= 0) return WDX_SUCCESS;
+    ClipArgs CA{A, d_rec, 6144, d_count, d_list};
+    const int64_t n_wg = (n_entries + kClipWaves - 1) / kClipWaves, max_slice = 1ll << 22;
+    for (int64_t base = 0; base < n_wg; base += max_slice) {
+        CA.a.block_base = base * kClipWaves;
+        hipLaunchKernelGGL(clip_bounds_list_kernel<96>, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)),
+                           dim3(kClipWaves * 64), 0, stream, CA);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t stream) {
     if (cap > 6144) {
         set_error("clip_bounds_kernel takes windows of at most 6144 samples");
         return WDX_ERR_INVALID;
     }
     void (*kclip)(ClipArgs) = cap <= 4096 ? clip_bounds_kernel<64> : (cap <= 5120 ? clip_bounds_kernel<80> : clip_bounds_kernel<96>);
-    ClipArgs CA{A, d_rec, cap};
+    ClipArgs CA{A, d_rec, cap, nullptr, nullptr};
     const int64_t n_wg = (A.n_reads + kClipWaves - 1) / kClipWaves, max_slice = 1ll << 22;
     for (int64_t base = 0; base < n_wg; base += max_slice) {
         CA.a.block_base = base * kClipWaves;

@@ -1689,9 +1689,17 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (combo == 3) capF = 6144;  // width 30 / reach 17: 115 VGPRs, four waves per SIMD either way
         // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
         // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
+        // Large batches: the clip bounds of the MAIN kernel's reads are computed ahead of it by clip_bounds_kernel (one wave
+        // per read, wdx_clip.hip) and the main kernel starts at the clip (EXT instantiation) with its peak list overlaying
+        // the consumed samples (fast_sh_offset): six workgroups per CU at 5120 samples, five at 6144.  The list kernels
+        // behind it (a tenth of the reads, longer windows) and small batches (live ticks: every launch counts) keep the
+        // in-kernel radix selects and the layout with the peak list behind the samples.
+        const bool ext = large_batch || capF == 5120;
+        const bool ovl = ext && (WDX_EXT_OVERLAY != 0);
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
+        if (ovl) capP = capF == 4096 ? 1400 : (capF == 5120 ? 1800 : 2040);  // (3 bytes per peak beside the samples)
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
-        const size_t flds = fast_lds_bytes(capF, capP, nbt);
+        const size_t flds = fast_lds_bytes(capF, capP, nbt, ovl);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
         int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads;
@@ -1710,11 +1718,6 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             F.big_count = count + 2;
             F.big_list = big1;
         }
-        // Large batches: the clip bounds of the MAIN kernel's reads are computed ahead of it by clip_bounds_kernel (one wave
-        // per read, wdx_clip.hip) and the main kernel starts at the clip (EXT instantiation).  The list kernels behind it
-        // (a tenth of the reads, longer windows) and small batches (live ticks: every launch counts) keep the in-kernel
-        // radix selects.
-        const bool ext = large_batch || capF == 5120;
         F.clip = ext ? clip : nullptr;
         void (*kern)(FastArgs) = nullptr;
         void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
@@ -1793,7 +1796,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
             const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
             FastArgs F1{A, capF1, capP1, count, list, with_big1 ? count + 2 : nullptr, with_big1 ? big1 : nullptr,
-                        count + 1, big0, 0u, F.retry_count, F.retry_list, nullptr};
+                        count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
+            if (int rc = launch_clip_bounds_list(A, clip, count + 1, big0, g1, stream)) return rc;
             launch_sliced(kern_l1, F1, g1, flds1, false);
             if (g1 < n_reads) {
                 FastArgs F1b{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big0, (unsigned)g1, F.retry_count,
@@ -1811,7 +1815,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // about 2 reads in 1000: a grid for 1/64 of the batch on the 6144-sample instantiation with exact scores
             // (a window beyond 6144 samples moves on to the slow path), the striding kernel beyond
             const int64_t g3 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 64));
-            FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr, nullptr};
+            FastArgs F3{A, capF1, capP1, count, list, nullptr, nullptr, count + 3, retry, 0u, nullptr, nullptr, clip};
             F3.a.exact_scores = 1;
             launch_sliced(kern_l1, F3, g3, flds1, false);
             if (g3 < n_reads) {
