@@ -425,7 +425,8 @@ def test_fast_kernels_of_the_other_shipped_triples(triple):
 @pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18)])
 def test_long_windows_in_large_batches_vs_oracle(triple):
     """3 000 reads whose windows straddle every capacity edge (5 120 / 6 144 / 8 192 / 11 200 / 16 384) through the
-    launch chain: the few beyond 11 200 samples reach fingerprint_big_kernel via the slow list."""
+    launch chain: windows of 8 193 .. 16 384 samples take the streaming fast kernel, and what it declines beyond 11 200
+    samples reaches fingerprint_big_kernel via the slow list."""
     E, d, w = triple
     rng = np.random.default_rng(E + d + w)
     n = 3000
@@ -433,6 +434,7 @@ def test_long_windows_in_large_batches_vs_oracle(triple):
     edge = [5119, 5120, 5121, 6144, 6145, 8192, 8193, 11199, 11200, 11201, 11264, 13000, 15200, 16383, 16384, 16385]
     lens[:len(edge)] = edge
     lens[100:140] = rng.integers(11201, 16385, 40)
+    lens[140:440] = rng.integers(8193, 16385, 300)     # the streaming fast kernel's range (fingerprint_fast_stream_kernel)
     stride = int(lens.max())
     mb = np.full((n, stride), np.nan, dtype=np.float32)
     for i, ln in enumerate(lens):

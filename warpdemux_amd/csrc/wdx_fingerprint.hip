@@ -1576,8 +1576,8 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
     return WDX_SUCCESS;
 }
 
-// four counters + four read lists (slow, big0, big1, retry: see launch_fingerprint) + one ClipRec per read
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 16 + 32 * (n_reads > 0 ? n_reads : 0); }
+// eight counters (five used) | one ClipRec per read | five read lists (slow, big0, big1, retry, big2: see launch_fingerprint)
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 36 * (n_reads > 0 ? n_reads : 0); }
 
 // The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
@@ -1700,25 +1700,33 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (ovl) capP = capF == 4096 ? 1400 : (capF == 5120 ? 1800 : 2040);  // (3 bytes per peak beside the samples)
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt, ovl);
-        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry
-        int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 16);
-        int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads;
-        WDX_HIP_TRY(hipMemsetAsync(count, 0, 16, stream));
+        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2
+        ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 32);
+        int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 32 + 16 * n_reads);
+        int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads, *big2 = retry + n_reads;
+        WDX_HIP_TRY(hipMemsetAsync(count, 0, 32, stream));
         const bool chain = !(d_prof && stop_phase > 0);         // (ablation timing: the main kernel alone)
         const bool with_big0 = chain && capF == 5120;            // windows of 5121..6144 samples, peak-list overflows
-        const bool with_big1 = chain && capF >= 5120 && cap > 6144;  // windows of 6145..8192 samples
+        // windows beyond 6144 samples, up to WDX_MAX_ADAPTER_SAMPLES: the streaming fast kernel (at 8 000 samples it is
+        // faster than the striding 8192-sample list kernel, which then only serves list overflows and exact-score retries)
+        const bool with_stream = chain && ext && capF >= 5120 && max_len > 6144;
+        const bool with_big1 = chain && capF >= 5120 && cap > 6144 && !with_stream;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
-        ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 16 + 16 * n_reads);
         FastArgs F{A, capF, capP, count, list, nullptr, nullptr, nullptr, nullptr, 0u, approx ? count + 3 : nullptr,
                    approx ? retry : nullptr, nullptr};
         if (with_big0) {
             F.big_count = count + 1;
             F.big_list = big0;
+        } else if (with_stream) {
+            F.big_count = count + 4;
+            F.big_list = big2;
         } else if (with_big1) {
             F.big_count = count + 2;
             F.big_list = big1;
         }
         F.clip = ext ? clip : nullptr;
+        void (*kern_st)(FastArgs) = combo == 2 ? fingerprint_fast_stream_kernel<18, 1>
+                                    : (combo == 3 ? fingerprint_fast_stream_kernel<30, 2> : fingerprint_fast_stream_kernel<kFW, 1>);
         void (*kern)(FastArgs) = nullptr;
         void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
         void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
@@ -1795,13 +1803,13 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // 11 % of RNA004 adapter windows are longer than 5120 samples: a grid for a quarter of the batch, one
             // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
             const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
-            FastArgs F1{A, capF1, capP1, count, list, with_big1 ? count + 2 : nullptr, with_big1 ? big1 : nullptr,
-                        count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
+            FastArgs F1{A, capF1, capP1, count, list, with_stream ? count + 4 : (with_big1 ? count + 2 : nullptr),
+                        with_stream ? big2 : (with_big1 ? big1 : nullptr), count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
             if (int rc = launch_clip_bounds_list(A, clip, count + 1, big0, g1, stream)) return rc;
             launch_sliced(kern_l1, F1, g1, flds1, false);
             if (g1 < n_reads) {
-                FastArgs F1b{A, capF2, capP2, count, list, nullptr, nullptr, count + 1, big0, (unsigned)g1, F.retry_count,
-                             F.retry_list, nullptr};
+                FastArgs F1b{A, capF2, capP2, count, list, with_stream ? count + 4 : nullptr, with_stream ? big2 : nullptr,
+                             count + 1, big0, (unsigned)g1, F.retry_count, F.retry_list, nullptr};
                 hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
                                    stream, F1b);
             }
@@ -1810,6 +1818,28 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list, nullptr};
             hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2, stream,
                                F2);
+        }
+        if (with_stream) {
+            // windows of 6145 .. 16384 samples (RNA002: max_obs_trace + 2 * padding = 15 200): their clip bounds by one
+            // workgroup per list entry (samples in LDS), then the streaming form of the fast body -- its LDS is the peak
+            // list plus two tile buffers, whatever the window length: four workgroups per CU up to 12 288 samples, three
+            // up to 16 384.  One workgroup per entry; the list's length is only known on the device, so the grid covers
+            // the batch (a workgroup past the list's end leaves at once).  Doubts and refusals go to the exact kernel.
+            const int scap = max_len <= 8192 ? 8192 : (max_len <= 12288 ? 12288 : 16384);
+            const int capPs = scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400);
+            const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
+            static LdsAttr attr_cb, attr_st[3];
+            if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
+            if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
+            const int64_t max_slice = 1ll << 22;
+            for (int64_t base = 0; base < n_reads; base += max_slice) {
+                ClipBlockArgs CB{A, clip, count + 4, big2, scap};
+                CB.a.block_base = base;
+                hipLaunchKernelGGL(clip_bounds_block_kernel, dim3((unsigned)std::min<int64_t>(max_slice, n_reads - base)), dim3(FB),
+                                   lds_cb, stream, CB);
+            }
+            FastArgs F5{A, 16384, capPs, count, list, nullptr, nullptr, count + 4, big2, 0u, nullptr, nullptr, clip};
+            launch_sliced(kern_st, F5, n_reads, lds_st, false);
         }
         if (approx && chain) {
             // about 2 reads in 1000: a grid for 1/64 of the batch on the 6144-sample instantiation with exact scores
@@ -1835,11 +1865,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (with_huge)
             if (int rc = launch_fp_big(A, cap, count, list, stream)) return rc;
         if (knobs.debug_occ) {  // (diagnostic: synchronises)
-            unsigned c[4] = {0, 0, 0, 0};
-            WDX_HIP_TRY(hipMemcpyAsync(c, count, 16, hipMemcpyDeviceToHost, stream));
+            unsigned c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            WDX_HIP_TRY(hipMemcpyAsync(c, count, 32, hipMemcpyDeviceToHost, stream));
             WDX_HIP_TRY(hipStreamSynchronize(stream));
-            fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u beyond 6144 samples, %u redone with "
-                            "exact scores, %u on the exact general kernel\n", (long long)n_reads, c[1], c[2], c[3], c[0]);
+            fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u to the 8192-sample list kernel, %u to the "
+                            "streaming kernel, %u redone with exact scores, %u on the exact general kernel\n", (long long)n_reads,
+                    c[1], c[2], c[4], c[3], c[0]);
             if (ext) {
                 std::vector<ClipRec> h((size_t)n_reads);
                 WDX_HIP_TRY(hipMemcpy(h.data(), clip, sizeof(ClipRec) * (size_t)n_reads, hipMemcpyDeviceToHost));
