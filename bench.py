@@ -408,11 +408,15 @@ def secondary_regimes(device):
     # ---- other shipped parameter triples on the fast kernels (device-resident fingerprint stage) + the tRNA config's
     # consensus-refinement flow (host batch; HIP-event time of the fingerprint launches) ------------------------------
     trip = {}
-    n_t = 262_144
-    for name, (E, d, W) in (("rna002_110_15_30", (110, 15, 30)), ("trna_120_9_18", (120, 9, 18))):
+    # (the third leg: the RNA002 triple on RNA002-LENGTH windows -- synth.dwell_table(2.5): dwell 15 + geometric(mean 71.75),
+    # mean window ~11.5 k samples, 8.3 k .. 15.6 k -- which is what that triple is for; ASSUMPTION stated in synth.py.
+    # These windows take the streaming fast kernel, fingerprint_fast_stream_kernel)
+    for name, (E, d, W), n_t, dscale in (("rna002_110_15_30", (110, 15, 30), 262_144, 1.0), ("trna_120_9_18", (120, 9, 18), 262_144, 1.0),
+                                         ("rna002_110_15_30_on_rna002_length_windows", (110, 15, 30), 65_536, 2.5)):
         pt = sig_proc.SegParams(num_events=E, min_obs_per_base=d, running_stat_width=W, barcode_num_events=25)
         engt = DemuxEngine(np.zeros((N_BARCODES, 25)), WINDOW, PENALTY, pt, device=device)
-        sg, of, s0, e0, _, mlen = engt.synth_packed(spec, 0, n_t)
+        spec_t = spec if dscale == 1.0 else synth.SynthSpec(n_barcodes=N_BARCODES, dwell_scale=dscale)
+        sg, of, s0, e0, _, mlen = engt.synth_packed(spec_t, 0, n_t)
         for _ in range(2):
             g = engt.fingerprint(sg, s0, e0, offsets=of, max_len=mlen)
         sync()
@@ -428,8 +432,13 @@ def secondary_regimes(device):
         ofp, odw, ost, ostat = orc.fingerprint_packed(sg[:int(o_h[-1])].cpu().numpy(), o_h, s0[:ns_].cpu().numpy(), e0[:ns_].cpu().numpy(),
                                                       orc.SegParams(num_events=E, min_obs_per_base=d, running_stat_width=W, barcode_num_events=25))
         okt = ostat == 0
-        trip[name] = {"reads_per_s": n_t / (sum(walls) / len(walls)), "ms": 1e3 * sum(walls) / len(walls), "ms_min": 1e3 * min(walls),
-                      "reads": n_t, "parity_reads": ns_,
+        rps = n_t / (sum(walls) / len(walls))
+        bpr = 4.0 * float(of[-1].item()) / n_t + 8.0 * 25 + 4.0    # algorithmic bytes per read of the fingerprint stage (K = 25)
+        trip[name] = {"reads_per_s": rps, "ms": 1e3 * sum(walls) / len(walls), "ms_min": 1e3 * min(walls),
+                      "reads": n_t, "mean_window_samples": float(of[-1].item()) / n_t, "max_window_samples": int(mlen),
+                      "roofline": {"bound": "hbm", "bytes_per_read": bpr, "achieved": rps * bpr / 1e9, "unit": "GB/s",
+                                   "peak": HBM_PEAK_GBS, "frac": rps * bpr / 1e9 / HBM_PEAK_GBS},
+                      "parity_reads": ns_,
                       "parity": bool(np.array_equal(g[3][:ns_].cpu().numpy(), ostat) and
                                      np.array_equal(g[0][:ns_].cpu().numpy()[okt].view(np.uint64), ofp[okt].view(np.uint64)) and
                                      np.array_equal(g[1][:ns_].cpu().numpy()[okt], odw[okt]))}
@@ -497,7 +506,8 @@ def secondary_regimes(device):
         trip["trna_refine_flow"] = None
     out["other_triples"] = {
         "workload": "fingerprint stage of the other shipped parameter triples (num_events, min_obs_per_base, running_stat_width) on "
-                    "262 144 device-resident synthetic reads, and the tRNA config's consensus-refinement flow on 8 192 host reads",
+                    "262 144 device-resident synthetic reads (RNA004-length windows), the RNA002 triple on 65 536 RNA002-length "
+                    "windows (dwell times x2.5: mean 11.5 k samples), and the tRNA config's consensus-refinement flow on 8 192 host reads",
         **trip, "parity": all(v.get("parity") is True for v in trip.values() if isinstance(v, dict))}
 
     leg_done("other_triples")

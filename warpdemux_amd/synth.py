@@ -55,12 +55,15 @@ def hash64(seed, read, stream, ctr):
     return z
 
 
-def dwell_table() -> np.ndarray:
-    """1024-entry inverse-CDF table: 6 + geometric(mean 28.7), capped at 400. int32."""
+def dwell_table(scale: float = 1.0) -> np.ndarray:
+    """1024-entry inverse-CDF table: 6 + geometric(mean 28.7), capped at 400 (int32) -- RNA004 at 130 bases/s.
+    ``scale`` stretches all three numbers: 2.5 gives the RNA002-like table 15 + geometric(mean 71.75), capped at 1000
+    (ASSUMPTION: the older chemistry's adapter windows are ~2.5x longer in samples -- its config's max_obs_trace,
+    min_obs_per_base and running_stat_width are 2.5x RNA004's, DEPRECATED/config_files/rna002_70bps@v0.4.4.toml:2-12)."""
     q = (np.arange(1024, dtype=np.float64) + 0.5) / 1024.0
-    p = 1.0 / 28.7
+    p = 1.0 / (28.7 * scale)
     g = np.floor(np.log1p(-q) / np.log1p(-p))
-    return (6 + np.minimum(g, 394)).astype(np.int32)
+    return (int(round(6 * scale)) + np.minimum(g, int(round(394 * scale)))).astype(np.int32)
 
 
 @dataclass
@@ -70,13 +73,14 @@ class SynthSpec:
     n_bc_events: int = 36
     noise_sigma: float = NOISE_SIGMA
     spikes: bool = True
+    dwell_scale: float = 1.0   # 2.5: RNA002-like dwell times (mean window ~11.6 k samples; see dwell_table)
 
     def tables(self):
         """(lead[N_LEAD], bc[n_barcodes, N_BC_TEMPLATE], dwell_table[1024]) -- float32/int32."""
         rng = np.random.Generator(np.random.PCG64(self.seed ^ 0x7E3A))
         lead = (80.0 + 15.0 * rng.standard_normal(N_LEAD)).astype(np.float32)
         bc = (80.0 + 15.0 * rng.standard_normal((self.n_barcodes, N_BC_TEMPLATE))).astype(np.float32)
-        return lead, bc, dwell_table()
+        return lead, bc, dwell_table(self.dwell_scale)
 
     @property
     def noise_scale(self) -> np.float32:
