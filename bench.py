@@ -60,6 +60,7 @@ def parse_args(argv=None):
                          "--cpu-seconds 0 verifies exactly this many")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--leg", default="", help="run ONE secondary leg alone and print its JSON (shipped_model_e2e)")
     ap.add_argument("--ctx-opt", action="append", default=[], metavar="ID=VALUE",
                     help="diagnostic: wdx_ctx_set_option(ID, VALUE) on the bench context (experiments only; the line "
                          "records it under config.ctx_options)")
@@ -282,6 +283,107 @@ def _oracle_dtw_threads(X, Y, budget_s=3.0, rows_per_job=32):
             outs += list(ex.map(lambda x: orc.dtw_matrix(x, Y, WINDOW, PENALTY), parts))
             done = hi
     return np.concatenate(outs), done
+
+
+def secondary_shipped_model_e2e(device):
+    import numpy as np
+    import torch
+
+    from oracle import wdx_oracle as orc
+    from warpdemux_amd import parallel_distances as pdist
+    from warpdemux_amd import sig_proc, synth
+    from warpdemux_amd.engine import DemuxEngine
+    from warpdemux_amd.models import DTW_SVM
+
+    out = {}
+    tdev = torch.device("cuda", device)
+
+    def sync():
+        torch.cuda.synchronize(tdev)
+
+    # ---- shipped_model_e2e: the shipped models' WHOLE path in one device-resident call (wdx_demux_svm_dev): raw rows ->
+    # fingerprint (K = 25) -> DTW against a WDX10-shaped training set (2 601 x 25-pt rows, 11 classes) -> SVM tail, the
+    # distance matrix in row blocks that stay in the memory-side cache.  The model is TRAINED here on fingerprints of
+    # synthetic reads of 11 barcodes (scikit-learn SVC on exp(-D), D from the engine), so the calls mean something:
+    # accuracy on the 10^5 held-out reads is reported next to the throughput. ---------------------------------------------
+    try:
+        from sklearn.svm import SVC
+
+        kcls, n_train, L, nq = 11, 2601, 25, 100_000
+        specm = synth.SynthSpec(n_barcodes=kcls)
+        pm = sig_proc.SegParams(barcode_num_events=L)
+        eng0 = DemuxEngine(np.zeros((1, L)), WINDOW, PENALTY, pm, device=device)
+        sgt, oft, st0, et0, bct, mlt = eng0.synth_packed(specm, 0, n_train + 64)
+        ftr, _, _, sttr = eng0.fingerprint(sgt, st0, et0, offsets=oft, max_len=mlt)
+        okt = (sttr == 0).cpu().numpy()
+        Xtr = ftr.cpu().numpy()[okt][:n_train]
+        ytr = bct.cpu().numpy()[okt][:n_train]
+        eng0.close()
+        Dtr = pdist.parallel_distance_matrix(Xtr, block_size=1000, n_jobs=1, window=WINDOW, penalty=PENALTY)
+        svc = SVC(kernel="precomputed", probability=True, random_state=0).fit(np.exp(-Dtr.astype(np.float64)), ytr)
+        sp = orc.svm_params(svc)
+        model = DTW_SVM(Xtr, *sp[:6], {i: i for i in range(kcls)}, None, WINDOW, PENALTY, block_size=1000, device=device)
+        engm = DemuxEngine(Xtr, WINDOW, PENALTY, pm, device=device)
+        engm.set_svm(model)
+        sgq, ofq, sq, eq, bcq, mlq = engm.synth_packed(specm, 1_000_000, nq)
+        res = engm.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq)          # allocates outputs, workspaces, the block buffer
+        for _ in range(2):
+            engm.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq, out=res)
+        sync()
+        walls = []
+        engm.kernel_time_reset()
+        engm.kernel_timing(True)
+        for _ in range(5):
+            sync()
+            t0 = time.perf_counter()
+            engm.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq, out=res)
+            sync()
+            walls.append(time.perf_counter() - t0)
+        engm.kernel_timing(False)
+        from warpdemux_amd import _lib as _l
+        kms = {nm: engm.kernel_time(kid)[0] / 5 for nm, kid in (("fingerprint", _l.K_FINGERPRINT), ("dtw", _l.K_DTW),
+                                                                 ("transpose", _l.K_TRANSPOSE), ("svm_tail", _l.K_SVM))}
+        # the same path as three separate calls with the whole (n, nY) matrix in HBM, for comparison
+        dfull = torch.empty((nq, n_train), dtype=torch.float32, device=engm.tdev)
+        walls3 = []
+        for rep in range(4):
+            sync()
+            t0 = time.perf_counter()
+            f3, _, _, s3 = engm.fingerprint(sgq, sq, eq, offsets=ofq, max_len=mlq)
+            engm.dtw(f3, want_argmin=False, out=(dfull, None))
+            p3 = engm.svm_predict(dfull)
+            sync()
+            if rep:
+                walls3.append(time.perf_counter() - t0)
+        prob, pred, conf, status = (t.cpu().numpy() for t in res[:4])
+        same3 = bool(np.array_equal(p3[0].cpu().numpy()[status == 0].view(np.uint64), prob[status == 0].view(np.uint64)))
+        ns = 512
+        o_h = ofq[: ns + 1].cpu().numpy()
+        ofp, _, _, ost = orc.fingerprint_packed(sgq[: int(o_h[-1])].cpu().numpy(), o_h, sq[:ns].cpu().numpy(), eq[:ns].cpu().numpy(),
+                                                orc.SegParams(barcode_num_events=L))
+        oko = ost == 0
+        pref = svc.predict_proba(np.exp(-orc.dtw_matrix(ofp[oko], Xtr, WINDOW, PENALTY)))
+        err = float(np.abs(prob[:ns][oko] - pref).max())
+        okq = status == 0
+        dt = sum(walls) / len(walls)
+        cells = 515.0 * n_train   # cells of the (25-pt, window 15) band x references, per read
+        out["shipped_model_e2e"] = {
+            "workload": "wdx_demux_svm_dev on 100 000 device-resident synthetic reads: fingerprint (K = 25) -> DTW vs 2 601 x 25-pt "
+                        "training rows (WDX10 shape, 11 classes; model trained here on synthetic fingerprints) -> SVM tail; distance "
+                        "matrix in cache-resident row blocks",
+            "reads_per_s": nq / dt, "ms": dt * 1e3, "ms_min": min(walls) * 1e3, "ms_max": max(walls) * 1e3, "reps": len(walls),
+            "kernels_ms": kms,      # HIP events around the library's launches
+            "three_separate_calls": {"reads_per_s": nq / (sum(walls3) / len(walls3)), "ms": 1e3 * sum(walls3) / len(walls3),
+                                     "same_probabilities_bitwise": same3},
+            "useful_cell_updates_per_s": nq * cells / dt,
+            "accuracy_on_ok_reads": float((pred[okq] == bcq.cpu().numpy()[okq]).mean()), "ok_reads": int(okq.sum()),
+            "parity": bool(err <= 1e-5 and same3 and np.array_equal(ost, status[:ns])), "max_abs_prob_err": err,
+            "parity_tolerance": 1e-5, "parity_reads": ns}
+        del dfull, res, sgq
+        engm.close()
+    except ImportError:
+        out["shipped_model_e2e"] = None
+    return out["shipped_model_e2e"]
 
 
 def secondary_regimes(device):
@@ -575,6 +677,8 @@ def secondary_regimes(device):
     except ImportError:
         out["dtw_svm_predict"] = None
     leg_done("dtw_svm_predict")
+    out["shipped_model_e2e"] = secondary_shipped_model_e2e(device)
+    leg_done("shipped_model_e2e")
     return out
 
 
@@ -897,6 +1001,10 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    if args.leg:
+        fn = {"shipped_model_e2e": secondary_shipped_model_e2e}[args.leg]
+        print(json.dumps({args.leg: fn(int(os.environ.get("LOCAL_RANK", "0")))}), flush=True)
+        return
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing in this process has touched the GPU
     run_rank(args)

@@ -296,6 +296,21 @@ int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m);
  * d_prob (n,k) float64 = y_prob, d_pred int32[n] = predicted barcode or -1, d_conf float64[n] = margin. */
 int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                         double *d_conf, void *stream);
+
+/* The shipped models' whole path in ONE device-resident call (file_proc.py:418-450 + models/dtw_svm.py:54-98 +
+ * models/utils.py:19-61): raw adapter rows -> fingerprint (K = the reference length) -> DTW against the resident
+ * training set -> exp(-gamma d^p) -> one-vs-one decision values -> Platt sigmoids + coupling -> process_probs.
+ * Inputs as wdx_demux_dev; needs wdx_set_refs and wdx_svm_set_model (a model trained on the resident set).
+ * The distance matrix is produced and consumed in row blocks of `block_rows` reads (0 = chosen so that a block is
+ * <= 96 MiB, i.e. stays in the 256 MB memory-side cache between the DTW kernel that writes it and the SVM tail that
+ * reads it) in a context-owned buffer; it is only written out in full when d_dist (n, nY) is given.
+ * Outputs DEVICE: d_status int32[n]; d_prob (n,k) float64, d_pred int32[n] (barcode label or -1), d_conf float64[n],
+ * each nullable; reads whose fingerprint failed get pred -1 and NaN probabilities / margin.  d_fpt (n,K) nullable.
+ * d_work: wdx_demux_workspace_bytes(n_reads, K) bytes.  Enqueued on `stream`; no synchronisation. */
+int wdx_demux_svm_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len, int64_t stride,
+                      int64_t max_len, int64_t n_reads, const int32_t *d_a_start, const int32_t *d_a_end,
+                      const uint8_t *d_ok, const wdx_seg_params *p, double *d_fpt, int32_t *d_status, float *d_dist,
+                      double *d_prob, int32_t *d_pred, double *d_conf, void *d_work, int64_t block_rows, void *stream);
 /* DTW_SVM.predict on host buffers: X (n, L) float64 fingerprints -> DTW against the resident reference
  * set (wdx_set_refs with model._X, window, penalty) -> SVM tail.  Outputs host, nullable. */
 int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf);

@@ -774,6 +774,60 @@ def test_dtw_svm_predict_matches_oracle_on_device_kernel_values():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("block_rows", [0, 2048])
+def test_demux_svm_dev_whole_path_matches_the_chained_calls_and_sklearn(block_rows):
+    """wdx_demux_svm_dev (raw rows -> fingerprint -> DTW vs the training set -> SVM tail, one device-resident call, the
+    distance matrix in row blocks) against (i) the same engine's three separate calls, bit for bit, and (ii) the oracle's
+    fingerprints + DTW with scikit-learn's own predict_proba / process_probs, 1e-5 on probabilities."""
+    pytest.importorskip("sklearn")
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    svc, Xtr, Xq, label_mapper, thr, m = _svm_case(5, 300, 8, seed=21, thresholds=True)
+    K = Xtr.shape[1]
+    spec = synth.SynthSpec(n_barcodes=4)
+    n = 5000
+    params = sig_proc.SegParams(barcode_num_events=K)
+    eng = DemuxEngine(Xtr, 15, 0.1, params)
+    eng.set_svm(m)
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 100, n)
+    a_e = a_e.clone()
+    a_e[::97] = a_s[::97] + 40                      # a few reads that fail (window too short for 110 events)
+    prob, pred, conf, status, dist, fpt = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len, want_dist=True,
+                                                        want_fpt=True, block_rows=block_rows)
+    torch.cuda.synchronize()
+    f2, _, _, st2 = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len)
+    d2, _ = eng.dtw(f2, want_argmin=False)
+    p2, q2, c2 = eng.svm_predict(d2)
+    torch.cuda.synchronize()
+    status, st2 = status.cpu().numpy(), st2.cpu().numpy()
+    ok = status == 0
+    assert np.array_equal(status, st2) and (~ok).sum() >= 50 and ok.sum() > 0.95 * n
+    assert _same(fpt.cpu().numpy()[ok], f2.cpu().numpy()[ok]) and _same(dist.cpu().numpy()[ok], d2.cpu().numpy()[ok])
+    assert _same(prob.cpu().numpy()[ok], p2.cpu().numpy()[ok]) and np.array_equal(pred.cpu().numpy()[ok], q2.cpu().numpy()[ok])
+    assert _same(conf.cpu().numpy()[ok], c2.cpu().numpy()[ok])
+    assert (pred.cpu().numpy()[~ok] == -1).all() and np.isnan(prob.cpu().numpy()[~ok]).all() and np.isnan(conf.cpu().numpy()[~ok]).all()
+    # without the distance / fingerprint outputs: the same answers from the context's own block buffer
+    pb, qb, cb, sb, _, _ = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len, block_rows=block_rows)
+    torch.cuda.synchronize()
+    assert _same(pb.cpu().numpy(), prob.cpu().numpy()) and np.array_equal(qb.cpu().numpy(), pred.cpu().numpy())
+    # against the oracle + scikit-learn on a sample
+    ns = 600
+    o = off[: ns + 1].cpu().numpy()
+    ofp, _, _, ost = orc.fingerprint_packed(sig[: int(o[-1])].cpu().numpy(), o, a_s[:ns].cpu().numpy(), a_e[:ns].cpu().numpy(),
+                                            orc.SegParams(barcode_num_events=K))
+    assert np.array_equal(ost, status[:ns])
+    oko = ost == 0
+    pred_ref, prob_ref, conf_ref = _reference_tail(svc, Xtr, ofp[oko], label_mapper, thr)
+    np.testing.assert_allclose(prob.cpu().numpy()[:ns][oko], prob_ref, rtol=0, atol=1e-5)
+    srt = np.sort(prob_ref, axis=1)
+    safe = ((srt[:, -1] - srt[:, -2]) > 1e-4) & (np.abs(conf_ref - thr[np.argmax(prob_ref, axis=1)]) > 1e-4)
+    assert np.array_equal(pred.cpu().numpy()[:ns][oko][safe], pred_ref[safe])
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_dtw_svm_predict_errors_and_single_row():
     pytest.importorskip("sklearn")
     svc, Xtr, Xq, label_mapper, thr, m = _svm_case(3, 150, 8, seed=4)

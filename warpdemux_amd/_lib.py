@@ -43,7 +43,7 @@ EXPORTS = [
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
     "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_refine_dev", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait",
     "wdx_host_alloc", "wdx_host_free", "wdx_live_tick", "wdx_svm_set_model",
-    "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_workspace_bytes", "wdx_demux_dev",
+    "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_svm_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
 ]
@@ -224,6 +224,8 @@ def load():
         L.wdx_demux_workspace_bytes.argtypes = [i64, i32]
         L.wdx_demux_dev.restype = C.c_int
         L.wdx_demux_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.wdx_demux_svm_dev.restype = C.c_int
+        L.wdx_demux_svm_dev.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, P(SegParamsC), vp, vp, vp, vp, vp, vp, vp, i64, vp]
         L.wdx_kernel_timing.restype = C.c_int
         L.wdx_kernel_timing.argtypes = [vp, C.c_int]
         L.wdx_kernel_time.restype = C.c_int

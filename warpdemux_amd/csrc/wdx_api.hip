@@ -1158,6 +1158,62 @@ int wdx_svm_predict_dev(wdx_ctx *ctx, const float *d_dist, int64_t n, double *d_
     return launch_svm_predict(ctx->svm, d_dist, n, d_prob, d_pred, d_conf, (hipStream_t)stream, ctx->knobs);
 }
 
+int wdx_demux_svm_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len, int64_t stride,
+                      int64_t max_len, int64_t n_reads, const int32_t *d_a_start, const int32_t *d_a_end,
+                      const uint8_t *d_ok, const wdx_seg_params *p, double *d_fpt, int32_t *d_status, float *d_dist,
+                      double *d_prob, int32_t *d_pred, double *d_conf, void *d_work, int64_t block_rows, void *stream) {
+    WDX_ENTER(ctx);
+    if (n_reads < 0 || !p || block_rows < 0 || (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_status || !d_work))) {
+        set_error("demux_svm_dev: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    DtwRefs &R = ctx->refs;
+    if (R.window == 0 || !ctx->svm_set) {
+        set_error("demux_svm_dev needs wdx_set_refs and wdx_svm_set_model first");
+        return WDX_ERR_NO_REFS;
+    }
+    if (R.nY != ctx->svm.n_train) {
+        set_error("reference set has %lld rows but the SVM was trained on %d", (long long)R.nY, ctx->svm.n_train);
+        return WDX_ERR_INVALID;
+    }
+    const int64_t K = p->barcode_num_events;
+    if (K != R.L) {
+        set_error("barcode_num_events (%lld) != reference length (%lld)", (long long)K, (long long)R.L);
+        return WDX_ERR_INVALID;
+    }
+    if (n_reads == 0) return WDX_SUCCESS;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = use_stream(ctx, s))) return rc;
+    if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
+    const int k = ctx->svm.k;
+    // rows per block: the (rows, nY) float32 distances of a block stay in the memory-side cache (<= 96 MiB)
+    int64_t rows = block_rows > 0 ? block_rows : (((int64_t)96 << 20) / (4 * R.nY)) / 64 * 64;
+    if (rows < 2048) rows = 2048;
+    if (rows > n_reads) rows = n_reads;
+    if (!d_dist && (rc = ctx->out0.ensure((size_t)(rows * R.nY) * 4))) return rc;
+    unsigned char *w = (unsigned char *)d_work;
+    double *fpt = d_fpt ? d_fpt : (double *)w;
+    void *fp_ws = w + ((n_reads * K * 8 + 255) / 256) * 256;   // (fingerprint workspace behind the fingerprints)
+    {
+        Timed t(ctx, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint(d_sig, d_row_off, d_row_len, stride, max_len, n_reads, d_a_start, d_a_end, d_ok, *p,
+                                     fpt, nullptr, nullptr, d_status, s, fp_ws, ctx->knobs, &t.n_launches, nullptr, 0, 0,
+                                     nullptr, &t.main, (double *)ctx->fp_big.p)))
+            return rc;
+    }
+    for (int64_t r0 = 0; r0 < n_reads; r0 += rows) {
+        const int64_t m = std::min(rows, n_reads - r0);
+        float *dblk = d_dist ? d_dist + r0 * R.nY : (float *)ctx->out0.p;
+        if ((rc = dtw_dev_locked(ctx, fpt + r0 * K, m, dblk, nullptr, s))) return rc;
+        Timed t(ctx, WDX_K_SVM, s);
+        if ((rc = launch_svm_predict(ctx->svm, dblk, m, d_prob ? d_prob + r0 * k : nullptr, d_pred ? d_pred + r0 : nullptr,
+                                     d_conf ? d_conf + r0 : nullptr, s, ctx->knobs)))
+            return rc;
+    }
+    return launch_svm_mask_failed(d_status, n_reads, k, d_prob, d_pred, d_conf, s);
+}
+
 int wdx_dtw_svm_predict(wdx_ctx *ctx, const double *X, int64_t n, double *prob, int32_t *pred, double *conf) {
     WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -149,6 +149,9 @@ struct SvmDev {  // device-resident SVC(kernel="precomputed", probability=True) 
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                        double *d_conf, hipStream_t stream, const Knobs &knobs);
 
+int launch_svm_mask_failed(const int32_t *d_status, int64_t n, int k, double *d_prob, int32_t *d_pred, double *d_conf,
+                           hipStream_t stream);
+
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream);
 
 }  // namespace wdx

@@ -344,6 +344,26 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
     }
 }
 
+// reads whose fingerprint failed carry NaN distances: the reference never shows them to the model
+// (file_proc.py:430-450 classifies the successful reads only) -> pred -1, probabilities / margin NaN
+__global__ void svm_mask_failed_kernel(const int32_t *__restrict__ status, int64_t n, int k, double *prob, int32_t *pred,
+                                       double *conf) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || status[r] == WDX_READ_OK) return;
+    if (pred) pred[r] = -1;
+    if (conf) conf[r] = __builtin_nan("");
+    if (prob)
+        for (int c = 0; c < k; ++c) prob[r * k + c] = __builtin_nan("");
+}
+int launch_svm_mask_failed(const int32_t *d_status, int64_t n, int k, double *d_prob, int32_t *d_pred, double *d_conf,
+                           hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(svm_mask_failed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_status, n, k, d_prob,
+                       d_pred, d_conf);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                        double *d_conf, hipStream_t stream, const Knobs &knobs) {
     if (n == 0) return WDX_SUCCESS;

@@ -170,6 +170,31 @@ class DemuxEngine:
                                               self._stream()))
         return prob, pred, conf
 
+    def demux_svm(self, sig, a_start, a_end, *, offsets=None, stride=0, max_len: int, ok=None, want_dist=False,
+                  want_fpt=False, block_rows: int = 0, out=None):
+        """The shipped models' whole path, device-resident (wdx_demux_svm_dev): raw rows -> fingerprint -> DTW against
+        the resident training set -> SVM tail.  Returns (prob f64 (n,k), pred i32 (n,), conf f64 (n,), status i32 (n,),
+        dist f32 (n,nY) or None, fpt f64 (n,K) or None); ``out`` = such a tuple from an earlier call is reused."""
+        torch = self.torch
+        n = int(a_start.shape[0])
+        if out is None:
+            out = (torch.empty((n, self.n_classes), dtype=torch.float64, device=self.tdev),
+                   torch.empty(n, dtype=torch.int32, device=self.tdev),
+                   torch.empty(n, dtype=torch.float64, device=self.tdev),
+                   torch.empty(n, dtype=torch.int32, device=self.tdev),
+                   torch.empty((n, self.nY), dtype=torch.float32, device=self.tdev) if want_dist else None,
+                   torch.empty((n, self.K), dtype=torch.float64, device=self.tdev) if want_fpt else None)
+        prob, pred, conf, status, dist, fpt = out
+        need = int(self.L.wdx_demux_workspace_bytes(n, self.K))
+        if self._work is None or self._work.numel() < need:
+            self._work = torch.empty(need, dtype=torch.uint8, device=self.tdev)
+        pc = self.params.to_c()
+        _lib.check(self.L.wdx_demux_svm_dev(
+            self.ctx.handle, _dp(sig), _dp(offsets), None, int(stride), int(max_len), n, _dp(a_start), _dp(a_end), _dp(ok),
+            C.byref(pc), _dp(fpt), _dp(status), _dp(dist), _dp(prob), _dp(pred), _dp(conf), _dp(self._work), int(block_rows),
+            self._stream()))
+        return out
+
     # -- synthetic inputs, generated in HBM ----------------------------------------------------------
     def synth_packed(self, spec: synth.SynthSpec, first_read: int, n_reads: int):
         """(sig f32[total], offsets i64[n+1], a_start i32[n], a_end i32[n], barcode i32[n]) on device,
