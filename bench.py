@@ -483,25 +483,32 @@ def secondary_regimes(device):
     # process keeps its context but is idle meanwhile.
     hw = {}
     t_hw = time.perf_counter()
-    for mode, refill, Ps in (("pipe", False, (1, 4, 8)), ("sync", False, (1, 4, 16)), ("pipe", True, (4,))):
+    # (jitter 2900: rows carry whole reads, adapter_start ~ U{100..3000} per read -- page-locked minibatches then take the
+    # packed staging, only the windows cross the bus; feeder: ONE GPU-facing process, P producer processes fill a shared
+    # page-locked ring -- always with the producers' own 40 MB fill per minibatch, like "pipe refill")
+    for mode, refill, Ps, jit in (("pipe", False, (1, 4), 0), ("pipe", False, (1, 2), 2900), ("sync", False, (1, 4, 16), 0),
+                                  ("sync", False, (1,), 2900), ("pipe", True, (4, 16), 2900), ("feeder", True, (4, 16), 2900)):
         for P in Ps:
+            key = "%s%s%s_P%d" % (mode, "_refill" if (refill and mode != "feeder") else "", "_jitter" if jit else "", P)
             cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
-                   "--seconds", "2"] + (["--refill"] if refill else [])
-            if time.perf_counter() - t_hw > 75.0:   # a slow box must not stretch the default run: the rest is skipped, and says so
-                hw["%s%s_P%d" % (mode, "_refill" if refill else "", P)] = {"skipped": "leg budget of 75 s spent"}
+                   "--seconds", "2", "--jitter", str(jit)] + (["--refill"] if (refill and mode != "feeder") else [])
+            if time.perf_counter() - t_hw > 90.0:   # a slow box must not stretch the default run: the rest is skipped, and says so
+                hw[key] = {"skipped": "leg budget of 90 s spent"}
                 continue
             try:
                 pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
                 rec = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
             except Exception as e:  # noqa: BLE001
                 rec = {"error": f"{type(e).__name__}: {e}"}
-            hw["%s%s_P%d" % (mode, "_refill" if refill else "", P)] = rec
+            hw[key] = rec
     good = [v for v in hw.values() if "reads_per_s" in v]
     out["host_workers"] = {
         "workload": "P forked worker processes on ONE GPU, each driving 1000 x 10 000 float32 minibatches (host buffers, PCIe "
                     "included) through fingerprint + DTW (110-pt x 10 refs) + call; sync = sig_proc.demux_batch on a pageable "
                     "array, pipe = MinibatchPipeline (page-locked buffers, wdx_demux_submit / wdx_demux_wait); refill = the "
-                    "worker copies a fresh minibatch into the buffer before every call",
+                    "worker copies a fresh minibatch into the buffer before every call; jitter = adapter_start ~ U{100..3000} per "
+                    "read (rows carry whole reads; page-locked rows then go through the packed staging); feeder = one GPU-facing "
+                    "process with 8 slots + P producer processes filling a shared page-locked ring",
         "host_cpus": effective_cores(), **hw,
         "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
         "parity": bool(good) and all(v.get("parity") is True for v in hw.values() if "skipped" not in v)}

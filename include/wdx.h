@@ -238,8 +238,9 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
                     int32_t *status);
 
 /* Pipelined form of wdx_demux_batch for the reference's worker loop (file_proc.py:380-454: fill minibatch k+1
- * while minibatch k is processed; 1197-1243: several such workers share one GPU).  A context has TWO slots, each
- * with its own stream and device workspaces:
+ * while minibatch k is processed; 1197-1243: several such workers share one GPU).  A context has WDX_MAX_SLOTS slots (the
+ * worker loop uses two; a feeder that serves many producers keeps more minibatches in flight), each with its own stream
+ * and device workspaces:
  *   wdx_demux_submit(ctx, slot, ...)  enqueues copy-in, fingerprint, DTW, call and copy-out of one minibatch on the
  *                                     slot's stream and returns; WDX_ERR_INVALID if the slot still holds a batch.
  *                                     The input arrays must stay untouched until the matching wait returns (rows in
@@ -248,7 +249,8 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
  *   wdx_demux_wait(ctx, slot, ...)    blocks until that minibatch is done and hands the results over (same outputs
  *                                     and meanings as wdx_demux_batch; fpt / dist only if requested at submit).
  * Submitting slot 1 while slot 0 is in flight overlaps its host->device copy with slot 0's kernels.  Results are
- * bit-identical to wdx_demux_batch.  wdx_set_refs waits for both slots before it changes the resident set. */
+ * bit-identical to wdx_demux_batch.  wdx_set_refs waits for every slot before it changes the resident set. */
+#define WDX_MAX_SLOTS 8
 int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_reads, int64_t stride,
                      const int32_t *a_start, const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
                      int64_t n_refs, int32_t want_fpt, int32_t want_dist);
@@ -257,6 +259,11 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
  * np.full): the GPU reads it directly.  Needs no context; free with wdx_host_free. */
 int wdx_host_alloc(size_t bytes, void **out);
 int wdx_host_free(void *p);
+/* Page-lock memory the caller already owns -- e.g. a shared-memory ring that producer PROCESSES fill while one feeder
+ * process owns the context and submits (tools/host_workers.py --mode feeder) -- so that it is read like wdx_host_alloc
+ * memory.  Undo with wdx_host_unregister before the memory is unmapped. */
+int wdx_host_register(void *p, size_t bytes);
+int wdx_host_unregister(void *p);
 
 /* Live path (BASELINE config 5; N4): every read of one 100 ms chunk round in one call -- the batched form of
  * live_balancing/worker.py:26-96 (segmentation_worker) + :99-131 (classification_worker).  rows[r] points at

@@ -395,6 +395,46 @@ def test_pipeline_run_with_two_rotating_buffers():
     pipe.close()
 
 
+def test_packed_staging_of_minibatches_with_jittered_adapter_starts():
+    """Rows that carry whole reads (adapter_start ~ U{100..3000}, sig_proc.py:382-391): a page-locked minibatch goes
+    through the packed staging (only the windows cross the bus, pack_windows_kernel), a pageable one through the 2-D
+    copy of the column union -- same bits either way, and the oracle's; incl. failed detections, a window clamped by
+    the row end, and an inverted window."""
+    from warpdemux_amd import pipeline
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K = 110
+    refs = np.random.default_rng(5).normal(size=(10, K))
+    params = sig_proc.SegParams(barcode_num_events=K)
+    n, stride = 1000, 10000
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 123456, n, stride, start_jitter=2900)
+    assert a_s.min() >= 100 and a_s.max() > 2500 and len(np.unique(a_s)) > 500
+    a_e = a_e.copy()
+    a_e[7] = stride + 50            # window clamped by the row end
+    a_e[11] = a_s[11] - 5           # inverted
+    ok = np.ones(n, dtype=np.uint8)
+    ok[::13] = 0
+    pin = pipeline.pinned_full((n, stride), np.nan, np.float32)
+    np.copyto(pin, mb)
+    sig_proc.set_references(refs, 15, 0.1)
+    got_pin = sig_proc.demux_batch(pin, a_s, a_e, params, success=ok, want_dist=True, want_fpt=True)
+    got_pag = sig_proc.demux_batch(mb, a_s, a_e, params, success=ok, want_dist=True, want_fpt=True)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=K), ok=ok)
+    good = status == 0
+    assert good.sum() > 850
+    D = orc.dtw_matrix(fpt[good], refs, 15, 0.1)
+    for got in (got_pin, got_pag):
+        assert np.array_equal(got.status, status) and np.array_equal(got.fpt[good].view(np.uint64), fpt[good].view(np.uint64))
+        assert np.array_equal(got.dist[good].view(np.uint32), D.view(np.uint32))
+        assert np.array_equal(got.call[good], orc.argmin_rows(D)) and (got.call[~good] == -1).all()
+    # and through the two-slot pipeline
+    pipe = pipeline.MinibatchPipeline(refs, 15, 0.1, params)
+    pipe.submit(0, pin, a_s, a_e, success=ok, want_fpt=True)
+    r = pipe.wait(0)
+    assert np.array_equal(r.status, status) and np.array_equal(r.dist[good].view(np.uint32), D.view(np.uint32))
+    pipe.close()
+
+
 @pytest.mark.timeout(400)
 def test_forked_workers_share_the_gpu_through_pipelines():
     """tools/host_workers.py: 4 forked workers x pipelined 1000-read minibatches on one GPU, oracle-checked."""

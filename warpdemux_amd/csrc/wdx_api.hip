@@ -399,10 +399,11 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws, &ctx->pk_idx})
         b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
+    ctx->pk_host.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int k = 0; k < kNumTimed; ++k)
         for (auto &e : ctx->pending[k]) {
@@ -863,17 +864,76 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
     if ((rc = B->out3.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = B->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     if ((rc = B->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
-    // (Letting the kernel read a page-locked minibatch in place over the bus -- no staging copy, only window samples
-    // cross -- was measured and lost: 1.80 M reads/s against 2.46 M with this DMA copy, which runs at 49 GB/s.)
-    const float *d_sig = (const float *)B->in0.p;
-    if (col1 > col0)
-        WDX_HIP_TRY(hipMemcpy2DAsync((float *)B->in0.p + col0, (size_t)stride * sizeof(float), sig + col0,
-                                     (size_t)stride * sizeof(float), (size_t)(col1 - col0) * sizeof(float),
-                                     (size_t)n_reads, hipMemcpyHostToDevice, s));
-    WDX_HIP_TRY(hipMemcpyAsync(B->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-    WDX_HIP_TRY(hipMemcpyAsync(B->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-    if (ok) WDX_HIP_TRY(hipMemcpyAsync(B->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
-    {
+    // (Letting the FINGERPRINT kernel read a page-locked minibatch in place over the bus was measured and lost: 1.80 M
+    // reads/s against 2.46 M with a DMA copy, which runs at 49 GB/s.)
+    // Two ways in.  (i) The 2-D DMA copy of the column range that holds every adapter window of the batch -- all a
+    // pageable array allows, and the best there is when every read's adapter starts at the same sample.  (ii) Rows that
+    // carry whole reads have their adapters at different places (sig_proc.py:382-391: adapter_start varies per read) and
+    // the column union is most of the row: when the minibatch is page-locked (wdx_host_alloc) and the windows are less
+    // than 0.85 of the union, a copy kernel reads ONLY the windows over the bus, back to back into a packed device
+    // buffer (pack_windows_kernel: pure copy, every load in flight), and the kernels run on the packed layout -- row r =
+    // the original row's samples [st_r, en_r), adapter bounds shifted by st_r: the same window, bit for bit.
+    int64_t win_total = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        if (ok && !ok[r]) continue;
+        int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
+        if (st < 0) st = 0;
+        if (en > stride) en = stride;
+        if (en > st) win_total += en - st;
+    }
+    const float *sig_dev = nullptr;  // the minibatch as the device sees it, when it is page-locked
+    if (col1 > col0 && (double)win_total < 0.85 * (double)((col1 - col0) * n_reads)) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, sig) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+            sig_dev = (const float *)at.devicePointer;
+        else
+            (void)hipGetLastError();
+    }
+    if (sig_dev) {
+        // host images (page-locked, owned by the slot until its copy has run): off int64[n+1] | st int32[n] | len
+        // int32[n] | a_start' int32[n] | a_end' int32[n]
+        const size_t ib = (size_t)(n_reads + 1) * 8 + (size_t)n_reads * 16;
+        if ((rc = B->pk_host.ensure(ib))) return rc;
+        if ((rc = B->pk_idx.ensure(ib))) return rc;
+        int64_t *h_off = (int64_t *)B->pk_host.p;
+        int32_t *h_st = (int32_t *)(h_off + n_reads + 1), *h_len = h_st + n_reads, *h_as = h_len + n_reads, *h_ae = h_as + n_reads;
+        int64_t acc = 0;
+        for (int64_t r = 0; r < n_reads; ++r) {
+            int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
+            if (st < 0) st = 0;
+            if (en > stride) en = stride;
+            if (en < st || (ok && !ok[r])) en = st;
+            st &= ~(int64_t)3;  // (up to three samples ahead of the window come along: 16-byte aligned bus reads)
+            h_off[r] = acc;
+            h_st[r] = (int32_t)st;
+            h_len[r] = (int32_t)(en - st);
+            h_as[r] = a_start[r] - (int32_t)st;
+            h_ae[r] = a_end[r] - (int32_t)st;
+            acc += ((en - st) + 3) & ~(int64_t)3;  // (rows start on 16-byte boundaries)
+        }
+        h_off[n_reads] = acc;
+        if ((rc = B->in0.ensure((size_t)(acc ? acc : 1) * sizeof(float)))) return rc;
+        WDX_HIP_TRY(hipMemcpyAsync(B->pk_idx.p, B->pk_host.p, ib, hipMemcpyHostToDevice, s));
+        const int64_t *d_off = (const int64_t *)B->pk_idx.p;
+        const int32_t *d_st = (const int32_t *)(d_off + n_reads + 1), *d_len = d_st + n_reads, *d_as = d_len + n_reads,
+                      *d_ae = d_as + n_reads;
+        if ((rc = launch_pack_windows(sig_dev, stride, n_reads, d_off, d_st, d_len, (float *)B->in0.p, s))) return rc;
+        if (ok) WDX_HIP_TRY(hipMemcpyAsync(B->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
+        Timed t(B, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint((const float *)B->in0.p, d_off, d_len, 0, max_len, n_reads, d_as, d_ae,
+                                     ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p, nullptr, nullptr,
+                                     (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
+                                     nullptr, (double *)B->fp_big.p)))
+            return rc;
+    } else {
+        const float *d_sig = (const float *)B->in0.p;
+        if (col1 > col0)
+            WDX_HIP_TRY(hipMemcpy2DAsync((float *)B->in0.p + col0, (size_t)stride * sizeof(float), sig + col0,
+                                         (size_t)stride * sizeof(float), (size_t)(col1 - col0) * sizeof(float),
+                                         (size_t)n_reads, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(B->in1.p, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(B->in2.p, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        if (ok) WDX_HIP_TRY(hipMemcpyAsync(B->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
         Timed t(B, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint(d_sig, nullptr, nullptr, stride, max_len, n_reads,
                                      (const int32_t *)B->in1.p, (const int32_t *)B->in2.p,
@@ -951,8 +1011,8 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
 // reference set: minibatch k+1's host->device copy runs while minibatch k's kernels and device->host copy are still
 // in flight, and the caller's thread is free to fill the next buffer in between.
 static int slot_get(wdx_ctx *ctx, int32_t slot, wdx_ctx **out) {
-    if (slot < 0 || slot >= 2) {
-        set_error("slot must be 0 or 1");
+    if (slot < 0 || slot >= WDX_MAX_SLOTS) {
+        set_error("slot must be in [0, %d)", WDX_MAX_SLOTS);
         return WDX_ERR_INVALID;
     }
     if (!ctx->slots[slot]) {
@@ -976,6 +1036,21 @@ int wdx_host_alloc(size_t bytes, void **out) {
         *out = nullptr;
         return e == hipErrorNoDevice ? WDX_ERR_NO_DEVICE : WDX_ERR_HIP;
     }
+    return WDX_SUCCESS;
+}
+
+int wdx_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) {
+        set_error("host_register: bad arguments");
+        return WDX_ERR_INVALID;
+    }
+    WDX_HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    return WDX_SUCCESS;
+}
+
+int wdx_host_unregister(void *p) {
+    if (!p) return WDX_SUCCESS;
+    WDX_HIP_TRY(hipHostUnregister(p));
     return WDX_SUCCESS;
 }
 
@@ -1038,7 +1113,7 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
     wdx_ctx *S = nullptr;
     {
         std::lock_guard<std::mutex> g(ctx->mu);
-        if (slot < 0 || slot >= 2 || !ctx->slots[slot] || !ctx->slots[slot]->slot_busy) {
+        if (slot < 0 || slot >= WDX_MAX_SLOTS || !ctx->slots[slot] || !ctx->slots[slot]->slot_busy) {
             set_error("demux_wait: nothing was submitted on slot %d", (int)slot);
             return WDX_ERR_INVALID;
         }

@@ -152,6 +152,10 @@ int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *
 int launch_svm_mask_failed(const int32_t *d_status, int64_t n, int k, double *d_prob, int32_t *d_pred, double *d_conf,
                            hipStream_t stream);
 
+// row r of a page-locked (n, stride) host minibatch, samples [st[r], st[r] + len[r]) -> dst + off[r] (device), read over
+// the bus by a copy kernel
+int launch_pack_windows(const float *src_dev, int64_t stride, int64_t n_reads, const int64_t *d_off, const int32_t *d_st,
+                        const int32_t *d_len, float *dst, hipStream_t stream);
 int launch_calib_read(const float *p, int64_t n, float *out, hipStream_t stream);
 
 }  // namespace wdx

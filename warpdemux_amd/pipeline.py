@@ -46,12 +46,29 @@ def pinned_full(shape, fill_value, dtype=np.float32) -> np.ndarray:
     return a
 
 
+MAX_SLOTS = 8   # WDX_MAX_SLOTS (include/wdx.h)
+
+
+def register_host(arr: np.ndarray):
+    """Page-lock memory the caller owns (wdx_host_register) -- e.g. a multiprocessing.shared_memory block that producer
+    processes fill while ONE feeder process owns the context.  Returns a finalizer-like callable that unregisters."""
+    L = _lib.load()
+    p = C.c_void_p(arr.ctypes.data)
+    _lib.check(L.wdx_host_register(p, C.c_size_t(arr.nbytes)))
+    return lambda: L.wdx_host_unregister(p)
+
+
 class MinibatchPipeline:
-    """Two minibatches in flight against one resident reference set (model._X)."""
+    """Minibatches in flight against one resident reference set (model._X): two slots for a worker's own loop, up to
+    MAX_SLOTS for a feeder process that serves many producers."""
 
     N_SLOTS = 2
 
-    def __init__(self, refs, window=None, penalty=None, params: Optional[SegParams] = None, device: int = 0):
+    def __init__(self, refs, window=None, penalty=None, params: Optional[SegParams] = None, device: int = 0,
+                 n_slots: int = 2):
+        if not 1 <= int(n_slots) <= MAX_SLOTS:
+            raise ValueError(f"n_slots must be in [1, {MAX_SLOTS}]")
+        self.N_SLOTS = int(n_slots)
         refs = np.ascontiguousarray(refs, dtype=np.float64)
         if refs.ndim != 2:
             raise ValueError("refs must be (nY, L)")
@@ -79,7 +96,7 @@ class MinibatchPipeline:
             raise ValueError("adapter_start/adapter_end must have one entry per read")
         ok = None if success is None else np.ascontiguousarray(success, dtype=np.uint8)
         if not 0 <= int(slot) < self.N_SLOTS:
-            raise ValueError("slot must be 0 or 1")
+            raise ValueError(f"slot must be in [0, {self.N_SLOTS})")
         _lib.check(self.L.wdx_demux_submit(self.ctx.handle, int(slot), _lib.ptr(sig), n, stride, _lib.ptr(a_s),
                                            _lib.ptr(a_e), _lib.ptr(ok), C.byref(self._pc), self.nY, int(want_fpt),
                                            int(want_dist)))

@@ -148,12 +148,33 @@ def generate_packed(spec: SynthSpec, first_read: int, n_reads: int):
     return sig, off, a_start, a_end, bc
 
 
-def generate_minibatch(spec: SynthSpec, first_read: int, n_reads: int, stride: int):
+def generate_minibatch(spec: SynthSpec, first_read: int, n_reads: int, stride: int, start_jitter: int = 0):
     """file_proc-style minibatch (file_proc.py:244-260): (n, stride) float32, NaN tail; rows longer
-    than ``stride`` are truncated like sig_preload_size truncates real reads."""
+    than ``stride`` are truncated like sig_preload_size truncates real reads.
+
+    ``start_jitter`` > 0: the rows carry WHOLE reads the way file_proc's do -- read r's adapter is preceded by
+    J_r = h(seed, r, 4, 0) mod (start_jitter + 1) samples of pre-adapter signal (open-pore-like, 95 pA with the
+    generator's noise statistics), so adapter_start = 100 + J_r varies per read (sig_proc.py:382-391 slices it
+    out); start_jitter = 2900 gives adapter_start ~ U{100 .. 3000}.  The adapter window itself is unchanged."""
     sig, off, a_start, a_end, bc = generate_packed(spec, first_read, n_reads)
     mb = np.full((n_reads, stride), np.nan, dtype=np.float32)
+    if start_jitter <= 0:
+        for i in range(n_reads):
+            row = sig[off[i] : off[i + 1]][:stride]
+            mb[i, : row.size] = row
+        return mb, a_start, a_end, bc
+    rid = np.arange(first_read, first_read + n_reads, dtype=np.uint64)
+    J = (hash64(spec.seed, rid, 4, 0) % np.uint64(start_jitter + 1)).astype(np.int64)
+    a_start, a_end = a_start.copy(), a_end.copy()
     for i in range(n_reads):
-        row = sig[off[i] : off[i + 1]][:stride]
+        j = int(J[i])
+        t = np.arange(j, dtype=np.uint64)
+        h = hash64(spec.seed, rid[i], 5, t)
+        isum = ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF)) + ((h >> np.uint64(32)) & np.uint64(0xFFFF)) +
+                (h >> np.uint64(48))).astype(np.float32) - np.float32(131070.0)
+        pre = (PRE_LEVEL + isum * spec.noise_scale).astype(np.float32)
+        row = np.concatenate([pre, sig[off[i] : off[i + 1]]])[:stride]
         mb[i, : row.size] = row
+        a_start[i] += j
+        a_end[i] += j
     return mb, a_start, a_end, bc
