@@ -66,6 +66,32 @@ def kkt_residuals(D, n_support, dual_coef, intercept, c_bound, gamma=1.0, pwr_di
             "n_free": n_free, "n_bound": n_bound, "n_zero": n_zero}
 
 
+def free_residuals(D, n_support, dual_coef, intercept, c_bound, gamma=1.0, pwr_dist=1):
+    """y f(x_s) - 1 of every free vector (0 < alpha_s < C_s) of every one-vs-one pair under the candidate D: the
+    ~2 000 (WDX4) .. ~9 000 (WDX10) EQUALITIES libsvm left behind, as one vector (for least-squares fits)."""
+    D = np.asarray(D)
+    K = np.exp(-gamma * np.power(D.astype(np.float32) if D.dtype == np.float32 else D, pwr_dist)).astype(np.float64)
+    out = []
+    for p, (i, j, ri, rj, row_i, row_j) in enumerate(pair_layout(n_support)):
+        idx = np.concatenate([ri, rj])
+        coef = np.concatenate([dual_coef[row_i, ri], dual_coef[row_j, rj]])
+        y = np.concatenate([np.ones(ri.size), -np.ones(rj.size)])
+        cb = np.concatenate([np.full(ri.size, c_bound[i]), np.full(rj.size, c_bound[j])])
+        alpha = coef * y
+        f = K[np.ix_(idx, idx)] @ coef + intercept[p]
+        free = (alpha > 1e-12) & (alpha < cb * (1.0 - 1e-9))
+        out.append((y * f - 1.0)[free])
+    return np.concatenate(out)
+
+
+def parabola_vertex(x, y):
+    """Abscissa of the vertex of the least-squares parabola through (x, y)."""
+    c2, c1, _ = np.polyfit(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), 2)
+    if not c2 > 0:
+        raise AssertionError("the residuals do not have a minimum inside the grid")
+    return -c1 / (2.0 * c2)
+
+
 def worst(res):
     """One number: the largest violation of any of the three conditions (<= eps when D is right)."""
     return max(res["free_max_abs"], res["bound_max"], -res["zero_min"])

@@ -45,3 +45,16 @@ def test_device_negative_controls_violate_the_kkt_conditions():
                "penalty_plus_10pct", "penalty_minus_10pct"):
         r = kkt.kkt_residuals(vs[vn](), m["n_support"], m["dual_coef"], m["intercept"], m["c_bound"], m["gamma"], m["pwr_dist"])
         assert kkt.worst(r) > 17 * EPS, (vn, r)
+
+
+@pytest.mark.parametrize("name", ["WDX4", "WDX4b", "WDX4c", "WDX6", "WDX10"])
+def test_device_fitted_penalty_and_scale_are_the_models_own(name):
+    """The least-squares fit of tests/test_oracle_dtw_kkt.py with the HIP kernels' distances, all five models: the
+    penalty / uniform scale that best explain the model's free-vector equalities are (0.1 within 0.5 %, 1 within 1e-4)."""
+    from test_oracle_dtw_kkt import fit_penalty_and_scale
+
+    g9 = np.load(G9)
+    m = kkt.model_from_npz(g9, name)
+    vp, vs, gp, gs = fit_penalty_and_scale(device_dtw, m)
+    assert abs(vp) <= 0.005 and abs(vs) <= 1e-4, (vp, vs)
+    assert gp == 0.0 and abs(gs) <= 5e-5, (gp, gs)
