@@ -258,6 +258,9 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
 /* Page-locked host memory for minibatch buffers the caller fills (what file_proc.py:244-260 allocates with
  * np.full): the GPU reads it directly.  Needs no context; free with wdx_host_free. */
 int wdx_host_alloc(size_t bytes, void **out);
+/* the same with `device` made current for the allocation (a multi-GPU worker whose context lives on device N: the
+ * plain call initialises HIP on the process's current device) */
+int wdx_host_alloc_on(int device, size_t bytes, void **out);
 int wdx_host_free(void *p);
 /* Page-lock memory the caller already owns -- e.g. a shared-memory ring that producer PROCESSES fill while one feeder
  * process owns the context and submits (tools/host_workers.py --mode feeder) -- so that it is read like wdx_host_alloc

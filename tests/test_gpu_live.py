@@ -353,7 +353,13 @@ def test_pipelined_minibatches_match_the_synchronous_call_and_the_oracle():
     pipe.submit(1, buf, a_s, a_e, want_fpt=False)
     with pytest.raises(ValueError):   # fpt was not requested at submit
         _lib.check(L.wdx_demux_wait(pipe.ctx.handle, 1, _lib.ptr(fpt), None, _lib.ptr(call), _lib.ptr(status)))
-    pipe._held[1] = None
+    with pytest.raises(ValueError):   # call / status are required
+        _lib.check(L.wdx_demux_wait(pipe.ctx.handle, 1, None, None, None, _lib.ptr(status)))
+    # an argument error leaves the minibatch in the slot: the wait can be repeated with the right arguments
+    with pytest.raises(ValueError):
+        pipe.submit(1, buf, a_s, a_e)
+    r1 = pipe.wait(1)
+    assert np.array_equal(r1.call, outs[0].call) and np.array_equal(r1.status, outs[0].status)
     # a new reference set while nothing is in flight: picked up by the next submit
     refs2 = np.random.default_rng(4).normal(size=(10, K))
     _lib.check(L.wdx_set_refs(pipe.ctx.handle, _lib.ptr(refs2), 10, K, 15, 0.1))

@@ -42,7 +42,7 @@ EXPORTS = [
     "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_available", "wdx_comm_info", "wdx_comm_unique_id", "wdx_comm_init",
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
     "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_refine_dev", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait",
-    "wdx_host_alloc", "wdx_host_free", "wdx_host_register", "wdx_host_unregister", "wdx_live_tick", "wdx_svm_set_model",
+    "wdx_host_alloc", "wdx_host_alloc_on", "wdx_host_free", "wdx_host_register", "wdx_host_unregister", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_svm_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
@@ -216,6 +216,8 @@ def load():
         L.wdx_host_alloc.argtypes = [C.c_size_t, P(vp)]
         L.wdx_host_free.restype = C.c_int
         L.wdx_host_free.argtypes = [vp]
+        L.wdx_host_alloc_on.restype = C.c_int
+        L.wdx_host_alloc_on.argtypes = [C.c_int, C.c_size_t, P(vp)]
         L.wdx_host_register.restype = C.c_int
         L.wdx_host_register.argtypes = [vp, C.c_size_t]
         L.wdx_host_unregister.restype = C.c_int

@@ -577,13 +577,24 @@ int wdx_fingerprint_refine_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     if ((rc = ctx->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
     const size_t qb = ((size_t)rp->n_query * 8 + 15) / 16 * 16;
-    if ((rc = ctx->ref_buf.ensure(qb))) return rc;
+    {
+        const void *before = ctx->ref_buf.p;
+        if ((rc = ctx->ref_buf.ensure(qb))) return rc;
+        if (ctx->ref_buf.p != before) ctx->ref_query_host.clear();  // (a new block: nothing is resident in it)
+    }
     const size_t wb = (size_t)fingerprint_refine_ws_bytes(n_reads);
     if ((rc = ctx->ref_ws.ensure(wb ? wb : 8))) return rc;
-    // the consensus comes from the host (84 doubles): a pageable copy, staged by the runtime before the call returns
-    WDX_HIP_TRY(hipMemcpyAsync(ctx->ref_buf.p, rp->query, (size_t)rp->n_query * 8, hipMemcpyHostToDevice, s));
+    // the consensus comes from the host (84 doubles) and is kept resident: uploaded only when its content changes, and
+    // then synchronously after the stream has drained (no reliance on how the runtime stages pageable copies)
+    if (ctx->ref_query_host.size() != (size_t)rp->n_query ||
+        memcmp(ctx->ref_query_host.data(), rp->query, (size_t)rp->n_query * 8) != 0) {
+        WDX_HIP_TRY(hipStreamSynchronize(s));
+        WDX_HIP_TRY(hipMemcpy(ctx->ref_buf.p, rp->query, (size_t)rp->n_query * 8, hipMemcpyHostToDevice));
+        ctx->ref_query_host.assign(rp->query, rp->query + rp->n_query);
+    }
     WDX_HIP_TRY(hipMemsetAsync(d_refine_idx, 0xff, (size_t)n_reads * 12, s));
-    WDX_HIP_TRY(hipMemsetAsync(ctx->ref_ws.p, 0, wb, s));
+    // (only the state word of every hand-over record: 4 of its 1632 bytes)
+    WDX_HIP_TRY(hipMemset2DAsync(ctx->ref_ws.p, (size_t)fingerprint_refine_ws_bytes(1), 0, 4, (size_t)n_reads, s));
     RefineDev *rf = nullptr;
     struct RfGuard {
         RefineDev *&r;
@@ -688,6 +699,7 @@ static int fingerprint_batch_impl(wdx_ctx *ctx, const float *sig, int64_t n_read
             return WDX_ERR_INVALID;
         }
         if ((rc = ctx->ref_buf.ensure(qb + (size_t)n_reads * 12))) return rc;
+        ctx->ref_query_host.clear();  // (this call's query replaces whatever wdx_fingerprint_refine_dev kept resident)
         WDX_HIP_TRY(hipMemcpyAsync(ctx->ref_buf.p, rp->query, (size_t)rp->n_query * 8, hipMemcpyHostToDevice, s));
         WDX_HIP_TRY(hipMemsetAsync((unsigned char *)ctx->ref_buf.p + qb, 0xff, (size_t)n_reads * 12, s));
         if ((rc = fill_refine_dev(*rp, (const double *)ctx->ref_buf.p, (int32_t *)((unsigned char *)ctx->ref_buf.p + qb),
@@ -1024,13 +1036,19 @@ static int slot_get(wdx_ctx *ctx, int32_t slot, wdx_ctx **out) {
     return WDX_SUCCESS;
 }
 
+int wdx_host_alloc_on(int device, size_t bytes, void **out) {
+    DeviceGuard guard(device);   // page-lock under the device that will read the buffer: no stray context on device 0
+    if (guard.rc) return guard.rc;
+    return wdx_host_alloc(bytes, out);
+}
+
 int wdx_host_alloc(size_t bytes, void **out) {
     if (!out) {
         set_error("host_alloc: null output");
         return WDX_ERR_INVALID;
     }
     *out = nullptr;
-    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
     if (e != hipSuccess) {
         set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         *out = nullptr;
@@ -1075,6 +1093,7 @@ int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_rea
     if ((rc = use_stream(ctx, ctx->stream))) return rc;
     WDX_HIP_TRY(hipStreamSynchronize(ctx->stream));
     S->knobs = ctx->knobs;
+    S->timing = ctx->timing;  // (timed like the parent's own launches; wdx_kernel_time sums the slots' events)
     S->refs = ctx->refs;  // device pointers of the parent's resident set (read-only; wdx_set_refs drains the slots)
     const DtwRefs &R = ctx->refs;
     const int64_t K = p->barcode_num_events;
@@ -1118,10 +1137,26 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
             return WDX_ERR_INVALID;
         }
         S = ctx->slots[slot];
+        // argument errors are reported BEFORE the wait and leave the minibatch in the slot: the caller can wait again
+        // with the right arguments; a second thread waiting on the same slot is refused
+        if (S->slot_waiting) {
+            set_error("demux_wait: another thread is waiting on slot %d", (int)slot);
+            return WDX_ERR_INVALID;
+        }
+        if (S->slot_n > 0 && (!call || !status)) {
+            set_error("demux_wait: call and status are required");
+            return WDX_ERR_INVALID;
+        }
+        if (S->slot_n > 0 && ((fpt && !S->slot_has_fpt) || (dist && !S->slot_has_dist && S->slot_nY > 0))) {
+            set_error("demux_wait: an output that was not requested at wdx_demux_submit");
+            return WDX_ERR_INVALID;
+        }
+        S->slot_waiting = true;
     }
-    // (the wait itself runs outside the parent's mutex: the other slot can be submitted meanwhile)
+    // (the wait itself runs outside the parent's mutex: the other slots can be submitted meanwhile)
     hipError_t e = S->slot_n > 0 ? hipStreamSynchronize(S->stream) : hipSuccess;
     std::lock_guard<std::mutex> g(ctx->mu);
+    S->slot_waiting = false;
     S->slot_busy = false;
     if (e != hipSuccess) {
         set_error("demux_wait: hipStreamSynchronize failed: %s", hipGetErrorString(e));
@@ -1129,14 +1164,6 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
     }
     const int64_t n = S->slot_n;
     if (n == 0) return WDX_SUCCESS;
-    if (!call || !status) {
-        set_error("demux_wait: call and status are required");
-        return WDX_ERR_INVALID;
-    }
-    if ((fpt && !S->slot_has_fpt) || (dist && !S->slot_has_dist && S->slot_nY > 0)) {
-        set_error("demux_wait: an output that was not requested at wdx_demux_submit");
-        return WDX_ERR_INVALID;
-    }
     const unsigned char *ho = (const unsigned char *)S->pin_out.p;
     memcpy(status, ho + S->slot_off[3], (size_t)n * 4);
     if (S->slot_nY > 0) memcpy(call, ho + S->slot_off[2], (size_t)n * 4);
@@ -1340,6 +1367,8 @@ int wdx_kernel_timing(wdx_ctx *ctx, int enable) {
     WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->timing = enable != 0;
+    for (wdx_ctx *S : ctx->slots)   // pipelined minibatches are timed on their slot's events
+        if (S) S->timing = ctx->timing;
     return WDX_SUCCESS;
 }
 
@@ -1350,34 +1379,49 @@ int wdx_kernel_time(wdx_ctx *ctx, int kernel_id, double *total_ms, int64_t *laun
         return WDX_ERR_INVALID;
     }
     std::lock_guard<std::mutex> g(ctx->mu);
-    for (size_t i = 0; i < ctx->pending[kernel_id].size(); ++i) {
-        auto &e = ctx->pending[kernel_id][i];
-        WDX_HIP_TRY(hipEventSynchronize(e.second));
-        float ms = 0;
-        WDX_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
-        ctx->acc_ms[kernel_id] += ms;
-        ctx->launches[kernel_id] += ctx->pending_launches[kernel_id][i];
-        ctx->pool.push_back(e);
+    double tot = 0.0;
+    int64_t nl = 0;
+    // the context's own launches and those of its pipeline slots (wdx_demux_submit enqueues on a slot's stream)
+    wdx_ctx *all[1 + WDX_MAX_SLOTS] = {ctx};
+    for (int k = 0; k < WDX_MAX_SLOTS; ++k) all[1 + k] = ctx->slots[k];
+    for (wdx_ctx *c : all) {
+        if (!c) continue;
+        for (size_t i = 0; i < c->pending[kernel_id].size(); ++i) {
+            auto &e = c->pending[kernel_id][i];
+            WDX_HIP_TRY(hipEventSynchronize(e.second));
+            float ms = 0;
+            WDX_HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+            c->acc_ms[kernel_id] += ms;
+            c->launches[kernel_id] += c->pending_launches[kernel_id][i];
+            c->pool.push_back(e);
+        }
+        c->pending[kernel_id].clear();
+        c->pending_launches[kernel_id].clear();
+        tot += c->acc_ms[kernel_id];
+        nl += c->launches[kernel_id];
     }
-    ctx->pending[kernel_id].clear();
-    ctx->pending_launches[kernel_id].clear();
-    if (total_ms) *total_ms = ctx->acc_ms[kernel_id];
-    if (launches) *launches = ctx->launches[kernel_id];
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = nl;
     return WDX_SUCCESS;
 }
 
 int wdx_kernel_time_reset(wdx_ctx *ctx) {
     WDX_ENTER(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
-    for (int k = 0; k < kNumTimed; ++k) {
-        for (auto &e : ctx->pending[k]) {
-            (void)hipEventSynchronize(e.second);
-            ctx->pool.push_back(e);
+    wdx_ctx *all[1 + WDX_MAX_SLOTS] = {ctx};
+    for (int k = 0; k < WDX_MAX_SLOTS; ++k) all[1 + k] = ctx->slots[k];
+    for (wdx_ctx *c : all) {
+        if (!c) continue;
+        for (int k = 0; k < kNumTimed; ++k) {
+            for (auto &e : c->pending[k]) {
+                (void)hipEventSynchronize(e.second);
+                c->pool.push_back(e);
+            }
+            c->pending[k].clear();
+            c->pending_launches[k].clear();
+            c->acc_ms[k] = 0;
+            c->launches[k] = 0;
         }
-        ctx->pending[k].clear();
-        ctx->pending_launches[k].clear();
-        ctx->acc_ms[k] = 0;
-        ctx->launches[k] = 0;
     }
     return WDX_SUCCESS;
 }

@@ -54,6 +54,7 @@ struct wdx_ctx {
     wdx::Buffer ref_ws;  // refinement branch: the fast kernels' hand-over records (fingerprint_refine_ws_bytes)
     wdx::Buffer fp_big;  // score curves of adapter windows beyond the exact kernel's LDS capacity (fingerprint_big_bytes)
     wdx::PinnedBuffer pin_in, pin_out;  // staging of small (live-tick sized) host-buffer calls
+    std::vector<double> ref_query_host;  // the consensus query resident in ref_buf (wdx_fingerprint_refine_dev uploads on change)
     wdx::Buffer pk_idx;       // packed staging of a page-locked minibatch: window offsets / first columns / shifted bounds
     wdx::PinnedBuffer pk_host;  // ... and their host images (kept until the slot's copy has run)
     int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes
@@ -63,7 +64,7 @@ struct wdx_ctx {
     // pipelined minibatches (wdx_demux_submit / wdx_demux_wait): up to WDX_MAX_SLOTS child contexts, each with its own stream and
     // workspaces, sharing this context's resident reference set; the fields below describe a child's batch in flight
     wdx_ctx *slots[WDX_MAX_SLOTS] = {};
-    bool slot_busy = false, slot_has_fpt = false, slot_has_dist = false;
+    bool slot_busy = false, slot_waiting = false, slot_has_fpt = false, slot_has_dist = false;
     int64_t slot_n = 0, slot_K = 0, slot_nY = 0;
     size_t slot_off[4] = {0, 0, 0, 0};
     // timing

@@ -116,6 +116,10 @@ class DemuxEngine:
         (fpt f64 (n,K), dwell i64 (n,K), stats f64 (n,6), refine_idx i32 (n,3), status i32), K = refine.barcode_keep_events."""
         torch = self.torch
         n = int(a_start.shape[0])
+        if offsets is None and not stride:
+            if sig.dim() != 2:
+                raise ValueError("packed reads need `offsets`, a minibatch needs 2-D `sig` or `stride`")
+            stride = int(sig.shape[1])     # (stride 0 would make every row alias row 0; ADVICE r3)
         K = int(refine.barcode_keep_events)
         fpt = torch.empty((n, K), dtype=torch.float64, device=self.tdev)
         dwell = torch.empty((n, K), dtype=torch.int64, device=self.tdev)

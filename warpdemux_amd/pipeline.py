@@ -25,23 +25,27 @@ from . import _lib
 from .sig_proc import DemuxBatch, SegParams
 
 
-def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
-    """Uninitialised NumPy array in page-locked host memory (wdx_host_alloc); freed with the array."""
+def pinned_empty(shape, dtype=np.float32, device: Optional[int] = None) -> np.ndarray:
+    """Uninitialised NumPy array in page-locked host memory (wdx_host_alloc); freed with the array.  ``device``: the
+    GPU whose context will read it (wdx_host_alloc_on: no stray HIP context on device 0 in a multi-GPU worker)."""
     dtype = np.dtype(dtype)
     shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     L = _lib.load()
     p = C.c_void_p()
-    _lib.check(L.wdx_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+    if device is None:
+        _lib.check(L.wdx_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+    else:
+        _lib.check(L.wdx_host_alloc_on(int(device), C.c_size_t(nbytes), C.byref(p)))
     buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
     arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
     weakref.finalize(buf, L.wdx_host_free, C.c_void_p(p.value))   # the ctypes block lives as long as any view of it
     return arr
 
 
-def pinned_full(shape, fill_value, dtype=np.float32) -> np.ndarray:
+def pinned_full(shape, fill_value, dtype=np.float32, device: Optional[int] = None) -> np.ndarray:
     """``np.full`` in page-locked memory: the drop-in for file_proc.py:244 (``np.full((n, m), np.nan, float32)``)."""
-    a = pinned_empty(shape, dtype)
+    a = pinned_empty(shape, dtype, device)
     a.fill(fill_value)
     return a
 
