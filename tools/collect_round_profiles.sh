@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -17,5 +17,8 @@ cp profiles/traffic.json gpurun_out/${TAG}_traffic.json 2>/dev/null
 python3 tools/collect_sq.py --tag ${TAG} --out gpurun_out/${TAG}_sq > gpurun_out/${TAG}_sq.log 2>&1
 python3 tools/phase_counters.py 262144 > gpurun_out/${TAG}_phase_counters.txt 2> gpurun_out/${TAG}_phase_counters.err
 python3 tools/profile_fingerprint.py 16384 1 1000000 > gpurun_out/${TAG}_fast_kernel_phase_shares.txt 2>&1
+python3 tools/long_window_bench.py 110 15 30 8192 > gpurun_out/${TAG}_window_lengths.txt 2>&1
+python3 tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine.txt 2>&1
+for t in "110 6 12" "110 15 30" "120 9 18"; do python3 tools/profile_exact.py $t 65536 >> gpurun_out/${TAG}_exact_kernel_triples.txt 2>&1; done
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_traffic gpurun_out/${TAG}_sq gpurun_out/phase_pmc
 ls -la gpurun_out | grep ${TAG}

@@ -89,6 +89,15 @@ def main():
         "launches_seen": fn,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/collect_traffic.py",
     }
+    # the launch ahead of the main kernel: clip_bounds_kernel reads the main kernel's samples once more
+    ck = [k for k in fetch if "clip_bounds_kernel" in k]
+    if ck:
+        cfk, cfn = fetch[ck[0]]
+        cwk, cwn = write.get(ck[0], (0.0, 1))
+        res["clip_bounds_kernel"] = {
+            "fetch_bytes_per_launch_corrected": cfk * 1024.0 * factor / cfn, "write_bytes_per_launch": cwk * 1024.0 / max(cwn, 1),
+            "launches_seen": cfn,
+            "algorithmic_bytes_per_step": (bj["roofline"].get("clip_bounds_kernel") or {}).get("algorithmic_bytes_per_step")}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
         json.dump(res, fh, indent=1)

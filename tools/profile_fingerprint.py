@@ -36,8 +36,8 @@ if fast:
           "3 plateau / peak-list capacity, 4 nbr, 5 kept-list capacity, 6 tie at the top-E cut, 7 doubt -> exact-scores retry):",
           np.bincount(dec[:, 13].astype(int), minlength=8).tolist())
 if fast:
-    names = ["P0 load", "P1a median", "P1b MAD+clip", "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E",
-             "P5 boundaries", "P6 event means", "P7 normalise"]
+    names = ["P0 load (+ clip: large batches)", "P1a median (small batches)", "P1b MAD+clip (small batches)",
+             "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E", "P5 boundaries", "P6 event means", "P7 normalise"]
     p = p[p[:, 9] != 0]   # reads the fast kernel finished (declined reads carry no end stamp)
 else:
     names = ["P0 load", "P1 median+clip", "P2 t-score", "P3a local maxima", "P3b suppression", "P4 top-E",
@@ -57,7 +57,7 @@ if fast:
     print("  score mode of the reads the main kernel finished (1 = approximate keys, 2 = exact scores):",
           np.bincount(p[:, 14].astype(int), minlength=3).tolist())
 
-if fast:
+if fast and (p[:, 16] != 0).any():   # (in-kernel medians: small batches only)
     q = p[:, 16:23]
     lab = ["minmax", "zero+hist", "scan+locate", "gather", "rank", "evenfix"]
     base = p[:, 1]
@@ -88,11 +88,14 @@ if fast and len(sys.argv) > 3:
     sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 0, nbig)
     status = torch.empty(nbig, dtype=torch.int32, device="cuda")
     prof1 = torch.zeros((1, 32), dtype=torch.int64, device="cuda")
-    names = ["P0 load", "P1a median", "P1b MAD+clip", "P2+P3a t-score+maxima", "P3b suppression", "P4 top-E",
-             "P5 boundaries", "P6 event means", "P7 normalise"]
+    # large batches run the EXT instantiation (clip bounds from clip_bounds_kernel, no medians in the kernel): its cuts are
+    # P0 (load + clip, stamp 3) and the phases behind it; the launch under test is the main kernel ALONE (stop_phase > 0
+    # switches the rest of the chain off), clip_bounds_kernel runs ahead of it and is listed first
+    names = {3: "P0 load + clip", 4: "P2+P3a t-score+maxima", 5: "P3b suppression", 6: "P4 top-E", 7: "P5 boundaries",
+             8: "P6 event means", 9: "P7 normalise"}
     prev = 0.0
-    print(f"ablation on {nbig} reads (ms per launch, cumulative / marginal):")
-    for k in [1, 21, 22, 23, 24] + list(range(2, 10)):
+    print(f"ablation on {nbig} reads (ms per launch of clip_bounds_kernel + the main kernel cut after the phase, cumulative / marginal):")
+    for k in range(3, 10):
         ts = []
         for rep in range(int(os.environ.get("WDX_PROF_REPS", "3"))):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -103,6 +106,5 @@ if fast and len(sys.argv) > 3:
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         t = min(ts)
-        nm = names[k - 1] if k < 20 else {21: "  med1: hist pass", 22: "  med1: scan+locate", 23: "  med1: gather", 24: "  med1: (rank) = all"}[k]
-        print(f"  after {nm:24s} {t:8.2f}  +{t - prev:7.2f}")
+        print(f"  after {names[k]:24s} {t:8.2f}  +{t - prev:7.2f}")
         prev = t
