@@ -321,7 +321,23 @@ def secondary_shipped_model_e2e(device):
         eng0.close()
         Dtr = pdist.parallel_distance_matrix(Xtr, block_size=1000, n_jobs=1, window=WINDOW, penalty=PENALTY)
         svc = SVC(kernel="precomputed", probability=True, random_state=0).fit(np.exp(-Dtr.astype(np.float64)), ytr)
-        sp = orc.svm_params(svc)
+        sp = list(orc.svm_params(svc))
+        n_sv_trained = int(sp[1].size)
+        # the shipped models' shape: EVERY training row is a support vector (tests/helpers/kkt.py).  This easy synthetic
+        # problem leaves most rows outside the margin, so the remaining rows of each class are appended as support vectors
+        # with zero coefficients: the same decision function (parity against scikit-learn still holds), the shipped
+        # models' amount of work -- the fused path only walks support vectors.
+        n_support, support, dual_coef = sp[0], sp[1], sp[2]
+        st = np.concatenate([[0], np.cumsum(n_support)])
+        sup2, coef2, ns2 = [], [], []
+        for c in range(kcls):
+            own = support[st[c]:st[c + 1]]
+            extra = np.setdiff1d(np.nonzero(ytr == svc.classes_[c])[0], own).astype(support.dtype)
+            sup2.append(np.concatenate([own, extra]))
+            coef2.append(np.concatenate([dual_coef[:, st[c]:st[c + 1]], np.zeros((kcls - 1, extra.size))], axis=1))
+            ns2.append(own.size + extra.size)
+        sp[0], sp[1], sp[2] = np.array(ns2, dtype=n_support.dtype), np.concatenate(sup2), np.ascontiguousarray(np.concatenate(coef2, axis=1))
+        assert sp[1].size == n_train
         model = DTW_SVM(Xtr, *sp[:6], {i: i for i in range(kcls)}, None, WINDOW, PENALTY, block_size=1000, device=device)
         engm = DemuxEngine(Xtr, WINDOW, PENALTY, pm, device=device)
         engm.set_svm(model)
@@ -356,7 +372,7 @@ def secondary_shipped_model_e2e(device):
             if rep:
                 walls3.append(time.perf_counter() - t0)
         prob, pred, conf, status = (t.cpu().numpy() for t in res[:4])
-        same3 = bool(np.array_equal(p3[0].cpu().numpy()[status == 0].view(np.uint64), prob[status == 0].view(np.uint64)))
+        same3 = bool(np.abs(p3[0].cpu().numpy()[status == 0] - prob[status == 0]).max() <= 1e-12)   # (another summation order)
         ns = 512
         o_h = ofq[: ns + 1].cpu().numpy()
         ofp, _, _, ost = orc.fingerprint_packed(sgq[: int(o_h[-1])].cpu().numpy(), o_h, sq[:ns].cpu().numpy(), eq[:ns].cpu().numpy(),
@@ -369,12 +385,14 @@ def secondary_shipped_model_e2e(device):
         cells = 515.0 * n_train   # cells of the (25-pt, window 15) band x references, per read
         out["shipped_model_e2e"] = {
             "workload": "wdx_demux_svm_dev on 100 000 device-resident synthetic reads: fingerprint (K = 25) -> DTW vs 2 601 x 25-pt "
-                        "training rows (WDX10 shape, 11 classes; model trained here on synthetic fingerprints) -> SVM tail; distance "
-                        "matrix in cache-resident row blocks",
+                        "training rows (WDX10 shape, 11 classes; model trained here on synthetic fingerprints, every row a support "
+                        "vector like the shipped models) with the SVM decision sums in the DTW kernel's epilogue -> sigmoids, "
+                        "coupling, process_probs; no distance matrix",
+            "support_vectors": int(sp[1].size), "support_vectors_with_nonzero_coefficients": n_sv_trained,
             "reads_per_s": nq / dt, "ms": dt * 1e3, "ms_min": min(walls) * 1e3, "ms_max": max(walls) * 1e3, "reps": len(walls),
             "kernels_ms": kms,      # HIP events around the library's launches
             "three_separate_calls": {"reads_per_s": nq / (sum(walls3) / len(walls3)), "ms": 1e3 * sum(walls3) / len(walls3),
-                                     "same_probabilities_bitwise": same3},
+                                     "same_probabilities_1e-12": same3},
             "useful_cell_updates_per_s": nq * cells / dt,
             "accuracy_on_ok_reads": float((pred[okq] == bcq.cpu().numpy()[okq]).mean()), "ok_reads": int(okq.sum()),
             "parity": bool(err <= 1e-5 and same3 and np.array_equal(ost, status[:ns])), "max_abs_prob_err": err,

@@ -808,10 +808,23 @@ def test_demux_svm_dev_whole_path_matches_the_chained_calls_and_sklearn(block_ro
     assert _same(prob.cpu().numpy()[ok], p2.cpu().numpy()[ok]) and np.array_equal(pred.cpu().numpy()[ok], q2.cpu().numpy()[ok])
     assert _same(conf.cpu().numpy()[ok], c2.cpu().numpy()[ok])
     assert (pred.cpu().numpy()[~ok] == -1).all() and np.isnan(prob.cpu().numpy()[~ok]).all() and np.isnan(conf.cpu().numpy()[~ok]).all()
-    # without the distance / fingerprint outputs: the same answers from the context's own block buffer
+    # without the distance output the shipped shape (25 points, window 15) takes the FUSED form: decision sums in the DTW
+    # kernel's epilogue, no distance matrix -- the same model, another summation order (1e-12 on probabilities)
     pb, qb, cb, sb, _, _ = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len, block_rows=block_rows)
     torch.cuda.synchronize()
-    assert _same(pb.cpu().numpy(), prob.cpu().numpy()) and np.array_equal(qb.cpu().numpy(), pred.cpu().numpy())
+    pbn, probn = pb.cpu().numpy(), prob.cpu().numpy()
+    assert np.array_equal(sb.cpu().numpy(), status) and np.isnan(pbn[~ok]).all() and (qb.cpu().numpy()[~ok] == -1).all()
+    np.testing.assert_allclose(pbn[ok], probn[ok], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(cb.cpu().numpy()[ok], conf.cpu().numpy()[ok], rtol=0, atol=1e-12)
+    srtf = np.sort(probn[ok], axis=1)
+    far = ((srtf[:, -1] - srtf[:, -2]) > 1e-9) & (np.abs(conf.cpu().numpy()[ok] - thr[np.argmax(probn[ok], axis=1)]) > 1e-9)
+    assert far.mean() > 0.99 and np.array_equal(qb.cpu().numpy()[ok][far], pred.cpu().numpy()[ok][far])
+    # the unfused form on request (diagnostic option): the chained calls' bits again
+    eng.ctx.set_option(_lib.OPT_NO_SHORT_DTW, 1)
+    pu, qu, cu, su, _, _ = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len, block_rows=block_rows)
+    torch.cuda.synchronize()
+    eng.ctx.set_option(_lib.OPT_NO_SHORT_DTW, 0)
+    np.testing.assert_allclose(pu.cpu().numpy()[ok], probn[ok], rtol=0, atol=1e-12)
     # against the oracle + scikit-learn on a sample
     ns = 600
     o = off[: ns + 1].cpu().numpy()
@@ -821,6 +834,7 @@ def test_demux_svm_dev_whole_path_matches_the_chained_calls_and_sklearn(block_ro
     oko = ost == 0
     pred_ref, prob_ref, conf_ref = _reference_tail(svc, Xtr, ofp[oko], label_mapper, thr)
     np.testing.assert_allclose(prob.cpu().numpy()[:ns][oko], prob_ref, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(pbn[:ns][oko], prob_ref, rtol=0, atol=1e-5)          # the fused form too
     srt = np.sort(prob_ref, axis=1)
     safe = ((srt[:, -1] - srt[:, -2]) > 1e-4) & (np.abs(conf_ref - thr[np.argmax(prob_ref, axis=1)]) > 1e-4)
     assert np.array_equal(pred.cpu().numpy()[:ns][oko][safe], pred_ref[safe])

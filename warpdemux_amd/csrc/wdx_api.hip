@@ -399,7 +399,7 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws, &ctx->pk_idx})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws, &ctx->pk_idx, &ctx->svm_fused, &ctx->svm_refs})
         b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -1239,6 +1239,32 @@ int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {
     S.n_train = m->n_train;
     S.pwr = m->pwr_dist;
     S.ngamma = (float)(-m->gamma);
+    // for the fused DTW + SVM path (wdx_demux_svm_dev): coefficients vector-major, two chunks per class
+    {
+        const int H = 2, nch = k * H;
+        const size_t cb = (size_t)nsv * (k - 1) * 8, ib = (size_t)(2 * nch + 1) * 4;
+        if ((rc = ctx->svm_fused.ensure(cb + ib))) return rc;
+        std::vector<unsigned char> hf(cb + ib);
+        double *ct = reinterpret_cast<double *>(hf.data());
+        for (int s_ = 0; s_ < nsv; ++s_)
+            for (int q = 0; q < k - 1; ++q) ct[(size_t)s_ * (k - 1) + q] = m->dual_coef[(size_t)q * nsv + s_];
+        int32_t *ref0 = reinterpret_cast<int32_t *>(hf.data() + cb), *slot = ref0 + nch + 1;
+        for (int c = 0; c < k; ++c) {
+            const int half = (m->n_support[c] + 1) / 2;
+            ref0[2 * c] = start[c];
+            ref0[2 * c + 1] = start[c] + half;
+            slot[2 * c] = 2 * c;
+            slot[2 * c + 1] = 2 * c + 1;
+        }
+        ref0[nch] = nsv;
+        WDX_HIP_TRY(hipMemcpy(ctx->svm_fused.p, hf.data(), hf.size(), hipMemcpyHostToDevice));
+        ctx->svm_coefT = reinterpret_cast<const double *>(ctx->svm_fused.p);
+        ctx->svm_chunk_ref0 = reinterpret_cast<const int32_t *>(reinterpret_cast<const unsigned char *>(ctx->svm_fused.p) + cb);
+        ctx->svm_chunk_slot = ctx->svm_chunk_ref0 + nch + 1;
+        ctx->svm_chunks = nch;
+        ctx->svm_halves = H;
+        ++ctx->svm_model_gen;
+    }
     ctx->svm_set = true;
     return WDX_SUCCESS;
 }
@@ -1293,7 +1319,9 @@ int wdx_demux_svm_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off
     int64_t rows = block_rows > 0 ? block_rows : (((int64_t)96 << 20) / (4 * R.nY)) / 64 * 64;
     if (rows < 2048) rows = 2048;
     if (rows > n_reads) rows = n_reads;
-    if (!d_dist && (rc = ctx->out0.ensure((size_t)(rows * R.nY) * 4))) return rc;
+    const bool fused = !d_dist && R.L == 25 && R.window == 15 && !ctx->knobs.no_short_dtw && !ctx->knobs.svm_scalar && k >= 2 &&
+                       k <= 16 && ctx->svm_chunks > 0;
+    if (!d_dist && !fused && (rc = ctx->out0.ensure((size_t)(rows * R.nY) * 4))) return rc;
     unsigned char *w = (unsigned char *)d_work;
     double *fpt = d_fpt ? d_fpt : (double *)w;
     void *fp_ws = w + ((n_reads * K * 8 + 255) / 256) * 256;   // (fingerprint workspace behind the fingerprints)
@@ -1303,6 +1331,37 @@ int wdx_demux_svm_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off
                                      fpt, nullptr, nullptr, d_status, s, fp_ws, ctx->knobs, &t.n_launches, nullptr, 0, 0,
                                      nullptr, &t.main, (double *)ctx->fp_big.p)))
             return rc;
+    }
+    // Fused form (the distances are not asked for, the shipped shape): dtw_short_svm_kernel over the references in
+    // support-vector order leaves the decision sums P[slot][q][read] -- 16 (k - 1) k bytes per read instead of 4 nY -- and
+    // the tail only adds them up, takes the sigmoids and runs the coupling.  No distance matrix, no row blocks.
+    if (fused) {
+        const SvmDev &M = ctx->svm;
+        if (ctx->svm_refs_gen != ctx->refs_gen || ctx->svm_refs_model_gen != ctx->svm_model_gen) {
+            const size_t rb = (size_t)M.n_sv * R.Lpad * 8;
+            if ((rc = ctx->svm_refs.ensure(rb + (size_t)M.n_sv))) return rc;
+            if ((rc = launch_gather_rows(R.pad, R.has_nan, M.support, M.n_sv, R.Lpad, (double *)ctx->svm_refs.p,
+                                         (uint8_t *)ctx->svm_refs.p + rb, s)))
+                return rc;
+            ctx->svm_refs_gen = ctx->refs_gen;
+            ctx->svm_refs_model_gen = ctx->svm_model_gen;
+        }
+        const size_t rb = (size_t)M.n_sv * R.Lpad * 8;
+        if ((rc = ctx->out0.ensure((size_t)ctx->svm_chunks * (k - 1) * (size_t)n_reads * 8))) return rc;
+        {
+            Timed t(ctx, WDX_K_DTW, s);
+            if ((rc = launch_dtw_svm_partial(fpt, n_reads, (const double *)ctx->svm_refs.p, R.Lpad, R.halo,
+                                             (const uint8_t *)ctx->svm_refs.p + rb, R.L, R.window, R.penalty, ctx->svm_coefT,
+                                             ctx->svm_chunk_ref0, ctx->svm_chunk_slot, ctx->svm_chunks, k - 1, M.pwr, M.ngamma,
+                                             (double *)ctx->out0.p, s)))
+                return rc;
+        }
+        {
+            Timed t(ctx, WDX_K_SVM, s);
+            if ((rc = launch_svm_finish(M, (const double *)ctx->out0.p, ctx->svm_halves, n_reads, d_prob, d_pred, d_conf, s)))
+                return rc;
+        }
+        return launch_svm_mask_failed(d_status, n_reads, k, d_prob, d_pred, d_conf, s);
     }
     for (int64_t r0 = 0; r0 < n_reads; r0 += rows) {
         const int64_t m = std::min(rows, n_reads - r0);

@@ -77,6 +77,14 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan /
                int32_t *d_argmin, void *d_scratch, int64_t scratch_bytes, hipStream_t stream,
                const Knobs &knobs, bool a_rowmajor = false);
 int64_t dtw_scratch_bytes(int64_t L, int window);
+// The shipped models' DTW (25 points, window 15) over references in support-vector order with the SVM decision sums in
+// its epilogue: P[slot][q][read] (wdx_dtw.hip: dtw_short_svm_kernel); gather of the resident references into that order.
+int launch_dtw_svm_partial(const double *X, int64_t nA, const double *Ypad_sv, int64_t Lpad, int halo, const uint8_t *y_nan_sv,
+                           int64_t L, int window, double penalty, const double *coefT, const int32_t *chunk_ref0,
+                           const int32_t *chunk_slot, int n_chunks, int km1, int pwr, float ngamma, double *P,
+                           hipStream_t stream);
+int launch_gather_rows(const double *src, const uint8_t *sflag, const int32_t *d_idx, int64_t n, int64_t ld, double *dst,
+                       uint8_t *dflag, hipStream_t stream);
 // anti-diagonal wavefront kernel for small problems (latency path)
 bool dtw_wavefront_eligible(int64_t nX, int64_t nY, int64_t L, int window, const Knobs &knobs);
 int launch_dtw_wavefront(const double *X, int64_t nX, const double *Ypad, int64_t Lpad, int halo,
@@ -149,6 +157,8 @@ struct SvmDev {  // device-resident SVC(kernel="precomputed", probability=True) 
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                        double *d_conf, hipStream_t stream, const Knobs &knobs);
 
+int launch_svm_finish(const SvmDev &M, const double *d_P, int halves, int64_t n, double *d_prob, int32_t *d_pred,
+                      double *d_conf, hipStream_t stream);
 int launch_svm_mask_failed(const int32_t *d_status, int64_t n, int k, double *d_prob, int32_t *d_pred, double *d_conf,
                            hipStream_t stream);
 

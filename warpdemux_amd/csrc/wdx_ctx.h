@@ -60,6 +60,13 @@ struct wdx_ctx {
     int64_t refs_gen = 0;  // bumped whenever the resident reference set (samples or window/penalty) changes
     wdx::SvmDev svm{};
     bool svm_set = false;
+    // fused DTW + SVM path of wdx_demux_svm_dev: vector-major coefficients and the chunk tables (built with the model),
+    // the resident references gathered into support-vector order (rebuilt when the reference set or the model changes)
+    wdx::Buffer svm_fused, svm_refs;
+    const double *svm_coefT = nullptr;
+    const int32_t *svm_chunk_ref0 = nullptr, *svm_chunk_slot = nullptr;
+    int svm_chunks = 0, svm_halves = 0;
+    int64_t svm_refs_gen = -1, svm_model_gen = 0, svm_refs_model_gen = -1;
     wdx::Comm *comm = nullptr;
     // pipelined minibatches (wdx_demux_submit / wdx_demux_wait): up to WDX_MAX_SLOTS child contexts, each with its own stream and
     // workspaces, sharing this context's resident reference set; the fields below describe a child's batch in flight

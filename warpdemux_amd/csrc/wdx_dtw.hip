@@ -554,6 +554,100 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
     return WDX_SUCCESS;
 }
 
+// ---- the shipped models' DTW with the SVM decision sums in its epilogue (wdx_demux_svm_dev; round 4) --------------
+// dtw_short_kernel's body over references in libsvm's SUPPORT-VECTOR order (grouped by class), one block (= one wave)
+// per 64 reads and CHUNK of one class's vectors.  Instead of writing the distance, the lane turns it into the kernel
+// value k = expf(-gamma d^p) (float32 like the reference, models/dtw_svm.py:21-22) and adds coef[q][s] * k to its k - 1
+// decision sums of that class -- P[q][c] = sum over the class's vectors -- kept in LDS (lane-private slots [q][lane]: the
+// DTW body uses no LDS and sits at 166 of the 168 VGPRs three waves per SIMD allow, so the sums cannot live in
+// registers).  A chunk's sums go to P[slot][q][read] (slot = class * halves + half); svm_finish sums the halves, adds
+// -rho and runs the sigmoids / coupling.  The (n, nY) distance matrix does not exist.  Summation order: the class's
+// vectors in order -- deterministic, no atomics.
+struct DtwSvmArgs {
+    const double *X;            // (nA, L) row-major fingerprints
+    int64_t nA;
+    const double *Ypad;         // references in support-vector order, padded rows
+    int64_t Lpad;
+    int halo;
+    const uint8_t *y_nan;       // per reference (support-vector order)
+    double p2;
+    const double *coefT;        // [n_sv][k - 1]: dual coefficients, vector-major
+    const int32_t *chunk_ref0;  // [n_chunks + 1] first vector of each chunk (chunks never straddle a class)
+    const int32_t *chunk_slot;  // [n_chunks] class * halves + half
+    int km1, pwr;
+    float ngamma;
+    double *P;                  // [n_slots][k - 1][nA]
+};
+template <int L, int W>
+__global__ __launch_bounds__(64, 3) void dtw_short_svm_kernel(DtwSvmArgs G) {
+    __shared__ double sums[16][64];
+    const int lane = threadIdx.x;
+    const int64_t a = (int64_t)blockIdx.x * 64 + lane;
+    const bool active = a < G.nA;
+    const int64_t al = active ? a : G.nA - 1;
+    const int b0 = G.chunk_ref0[blockIdx.y], b1 = G.chunk_ref0[blockIdx.y + 1];
+    const int km1 = G.km1;
+    double x[L];
+    bool anan = false;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        x[i] = G.X[al * (int64_t)L + i];
+        anan |= x[i] != x[i];
+    }
+    for (int q = 0; q < km1; ++q) sums[q][lane] = 0.0;
+    for (int b = b0; b < b1; ++b) {
+        const double *__restrict__ y = G.Ypad + (int64_t)b * G.Lpad + G.halo;
+        double D[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
+        dtw_short_rows<L, W>(D, x, y, G.p2, std::make_integer_sequence<int, L>{});
+        double res = sqrt(D[L - 1]);
+        if (anan || (G.y_nan && G.y_nan[b])) res = __builtin_nan("");
+        const float d = (float)res;   // the float32 distance distance_matrix_to returns (parallel_distances.py:59-67)
+        const float t = G.pwr == 1 ? d : (G.pwr == 2 ? d * d : powf(d, (float)G.pwr));
+        const double kv = (double)expf(G.ngamma * t);
+        const double *__restrict__ cf = G.coefT + (int64_t)b * km1;   // uniform: scalar loads
+        for (int q = 0; q < km1; ++q) sums[q][lane] += cf[q] * kv;
+    }
+    if (active) {
+        double *__restrict__ Pq = G.P + ((int64_t)G.chunk_slot[blockIdx.y] * km1) * G.nA + a;
+        for (int q = 0; q < km1; ++q) Pq[(int64_t)q * G.nA] = sums[q][lane];
+    }
+}
+
+int launch_dtw_svm_partial(const double *X, int64_t nA, const double *Ypad_sv, int64_t Lpad, int halo, const uint8_t *y_nan_sv,
+                           int64_t L, int window, double penalty, const double *coefT, const int32_t *chunk_ref0,
+                           const int32_t *chunk_slot, int n_chunks, int km1, int pwr, float ngamma, double *P,
+                           hipStream_t stream) {
+    if (nA == 0 || n_chunks == 0) return WDX_SUCCESS;
+    if (L != 25 || window != 15 || km1 < 1 || km1 > 15) {
+        set_error("the fused DTW + SVM path serves the shipped shape (25-point fingerprints, window 15, <= 16 classes)");
+        return WDX_ERR_UNSUPPORTED;
+    }
+    DtwSvmArgs G{X, nA, Ypad_sv, Lpad, halo, y_nan_sv, penalty * penalty, coefT, chunk_ref0, chunk_slot, km1, pwr, ngamma, P};
+    dim3 grid((unsigned)((nA + 63) / 64), (unsigned)n_chunks);
+    hipLaunchKernelGGL((dtw_short_svm_kernel<25, 15>), grid, dim3(64), 0, stream, G);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
+// rows of `src` (n_src, ld) gathered by index into `dst` (n, ld), plus their byte flags: the resident references in
+// support-vector order
+__global__ void gather_rows_kernel(const double *__restrict__ src, const uint8_t *__restrict__ sflag, const int32_t *__restrict__ idx,
+                                   int64_t n, int64_t ld, double *__restrict__ dst, uint8_t *__restrict__ dflag) {
+    const int64_t r = blockIdx.x;
+    const int64_t s = idx[r];
+    for (int64_t i = threadIdx.x; i < ld; i += blockDim.x) dst[r * ld + i] = src[s * ld + i];
+    if (threadIdx.x == 0 && dflag) dflag[r] = sflag ? sflag[s] : 0;
+}
+int launch_gather_rows(const double *src, const uint8_t *sflag, const int32_t *d_idx, int64_t n, int64_t ld, double *dst,
+                       uint8_t *dflag, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(64), 0, stream, src, sflag, d_idx, n, ld, dst, dflag);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 // ---- layout helpers ----------------------------------------------------------------------------
 
 __global__ void transpose_kernel(const double *__restrict__ src, int64_t n, int64_t L,

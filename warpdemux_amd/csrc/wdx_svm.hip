@@ -166,11 +166,14 @@ __global__ __launch_bounds__(256) void svm_predict_kernel(SvmDev M, const float 
 // scikit-learn at ~1e-7 relative anyway, tolerances in tests/.)
 typedef double wdx_d4 __attribute__((ext_vector_type(4)));
 
-template <bool PWR1>  // pwr_dist == 1 (every shipped model): no powf in the inner loop
+// FROMP: the decision sums come from the DTW kernel's epilogue (dtw_short_svm_kernel: Psum[slot][q][read], slot =
+// class * halves + half) instead of the distance matrix; phase 1 then only adds them up.
+template <bool PWR1, bool FROMP = false>  // pwr_dist == 1 (every shipped model): no powf in the inner loop
 __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const float *__restrict__ dist,
                                                               int64_t n, double *__restrict__ prob,
                                                               int32_t *__restrict__ pred,
-                                                              double *__restrict__ conf) {
+                                                              double *__restrict__ conf,
+                                                              const double *__restrict__ Psum = nullptr, int halves = 0) {
     extern __shared__ double svm_lds[];  // dec[16][npairs] | 4 x pw[k*k]
     const int k = M.k, npairs = k * (k - 1) / 2;
     const int lane = threadIdx.x;
@@ -181,6 +184,27 @@ __global__ __launch_bounds__(64) void svm_predict_mfma_kernel(SvmDev M, const fl
     for (int idx = lane; idx < 16 * npairs; idx += 64) dec[idx] = -M.rho[idx % npairs];
     __builtin_amdgcn_wave_barrier();
 
+    if constexpr (FROMP) {
+        // value of pair (i < j) = P[q = j - 1][class i] + P[q = i][class j] - rho  (svm.cpp svm_predict_values), each P the
+        // sum of the class's halves in order
+        for (int idx = lane; idx < 16 * npairs; idx += 64) {
+            const int rl = idx / npairs, p = idx - rl * npairs;
+            int i = 0, rem = p;
+            while (rem >= k - 1 - i) {
+                rem -= k - 1 - i;
+                ++i;
+            }
+            const int j = i + 1 + rem;
+            const int64_t rr = r0 + rl < n ? r0 + rl : n - 1;
+            double a = 0.0, b = 0.0;
+            for (int h = 0; h < halves; ++h) {
+                a += Psum[((int64_t)(i * halves + h) * (k - 1) + (j - 1)) * n + rr];
+                b += Psum[((int64_t)(j * halves + h) * (k - 1) + i) * n + rr];
+            }
+            dec[idx] += a + b;
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else
     // ---- phase 1: decision values through the matrix cores
     {
         const int ar = lane & 15, kk = lane >> 4;  // A: read ar, B: coefficient row ar; both: support vector kk of the step
@@ -364,14 +388,35 @@ int launch_svm_mask_failed(const int32_t *d_status, int64_t n, int k, double *d_
     return WDX_SUCCESS;
 }
 
+// sigmoids + coupling + process_probs from the decision sums the DTW epilogue left (dtw_short_svm_kernel)
+int launch_svm_finish(const SvmDev &M, const double *d_P, int halves, int64_t n, double *d_prob, int32_t *d_pred,
+                      double *d_conf, hipStream_t stream) {
+    if (n == 0) return WDX_SUCCESS;
+    const int k = M.k;
+    if (k < 2 || k > 16) {
+        set_error("the fused SVM tail takes 2..16 classes");
+        return WDX_ERR_UNSUPPORTED;
+    }
+    const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (size_t)k * k);
+    void (*kern)(SvmDev, const float *, int64_t, double *, int32_t *, double *, const double *, int) =
+        svm_predict_mfma_kernel<true, true>;
+    static LdsAttr attr;
+    if (int rc = attr.ensure(kern, lds2)) return rc;
+    const int64_t tiles = (n + 15) / 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), lds2, stream, M, (const float *)nullptr, n, d_prob, d_pred, d_conf,
+                       d_P, halves);
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *d_prob, int32_t *d_pred,
                        double *d_conf, hipStream_t stream, const Knobs &knobs) {
     if (n == 0) return WDX_SUCCESS;
     const int k = M.k;
     if (k >= 2 && k <= 16 && !knobs.svm_scalar) {
         const size_t lds2 = sizeof(double) * ((size_t)16 * k * (k - 1) / 2 + 4 * (size_t)k * k);
-        void (*kern)(SvmDev, const float *, int64_t, double *, int32_t *, double *) =
-            M.pwr == 1 ? svm_predict_mfma_kernel<true> : svm_predict_mfma_kernel<false>;
+        void (*kern)(SvmDev, const float *, int64_t, double *, int32_t *, double *, const double *, int) =
+            M.pwr == 1 ? svm_predict_mfma_kernel<true, false> : svm_predict_mfma_kernel<false, false>;
         static LdsAttr attr[2];
         if (int rc = attr[M.pwr == 1].ensure(kern, lds2)) return rc;
         const int64_t tiles = (n + 15) / 16;
@@ -381,7 +426,7 @@ int launch_svm_predict(const SvmDev &M, const float *d_dist, int64_t n, double *
             const int64_t rb = base * 16, rn = n - rb < m * 16 ? n - rb : m * 16;
             hipLaunchKernelGGL(kern, dim3((unsigned)m), dim3(64), lds2, stream, M,
                                d_dist + rb * M.n_train, rn, d_prob ? d_prob + rb * k : nullptr,
-                               d_pred ? d_pred + rb : nullptr, d_conf ? d_conf + rb : nullptr);
+                               d_pred ? d_pred + rb : nullptr, d_conf ? d_conf + rb : nullptr, (const double *)nullptr, 0);
         }
         WDX_HIP_TRY(hipGetLastError());
         return WDX_SUCCESS;
