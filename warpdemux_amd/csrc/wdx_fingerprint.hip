@@ -1468,7 +1468,9 @@ static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list
     for (int64_t base = 0; base < A.n_reads; base += slice) {
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
-        hipLaunchKernelGGL((fingerprint_refine_match_kernel<128>), dim3((unsigned)n), dim3(128), lds_m, stream, A);
+        static const bool old_match = getenv("WDX_REFINE_MATCH_OLD") != nullptr;
+        if (old_match) hipLaunchKernelGGL((fingerprint_refine_match_kernel<128>), dim3((unsigned)n), dim3(128), lds_m, stream, A);
+        else if (int rc = launch_refine_match_wave(A, n, stream)) return rc;
         hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
                            slow_list);
     }

@@ -103,4 +103,8 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
                             hipStream_t stream);
 
+// the subsequence match of the consensus refinement for the reads a fast kernel segmented (RefineRec::state == 1), reads
+// block_base .. block_base + n of A: one wave per group of reads (wdx_refine_match.hip)
+int launch_refine_match_wave(FpArgs A, int64_t n, hipStream_t stream);
+
 }  // namespace wdx
