@@ -46,6 +46,8 @@ def timed(fn, reps=5):
     return ms.value / reps, out
 
 
+if os.environ.get("WDX_DEBUG_OCC"):
+    ctx.set_option(_lib.OPT_DEBUG_OCCUPANCY, 1)
 t_plain, fb = timed(lambda: sig_proc.fingerprint_batch(mb, a_s, a_e, seg))
 t_ref, fr = timed(lambda: sig_proc.fingerprint_refine_batch(mb, a_s, a_e, seg, ref))
 print(f"{n} reads, mean window {float((a_e - a_s + 200).mean()):.0f} samples")

@@ -1075,6 +1075,8 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
 
     WDX_STAMP(1);
     // ---- P1: MAD outlier clip (sig_proc.py:421-431), float32 ---------------------------------------
+    int any_nan = 0;          // (this thread saw a NaN sample / the bounds are NaN: only the refinement hand-over asks)
+    float clip_lo = 0.f, clip_hi = 0.f;
     {
         const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
         const float mad =
@@ -1092,9 +1094,14 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
                     if (!(v < hi)) v = hi;
                 }
                 sig[i] = v;
+            } else {
+                any_nan = 1;
             }
         }
         __syncthreads();
+        clip_lo = lo;
+        clip_hi = hi;
+        if (bad) any_nan = 1;
     }
 
     WDX_STAMP(2);
@@ -1206,6 +1213,22 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     }
     WDX_STAMP(7);
     if (A.rf.query) {
+        // The refinement kernels behind the fast kernels (one wave per three reads for the match, a quarter of this
+        // workgroup for the barcode's segmentation) take this read too when they can reproduce its clipped samples from
+        // the recorded bounds: no NaN in the window, samples as loaded, the configured window width.
+        if (A.refine_record && A.rf.ws && P.sig_norm == WDX_NORM_NONE && W == P.running_stat_width && nseg <= 128 &&
+            !__syncthreads_or(any_nan)) {
+            RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
+            for (int s = tid; s < nseg; s += BLOCK) rec->ev[s] = ev[s];
+            for (int s = tid; s <= nseg; s += BLOCK) rec->cpts[s] = cpts[s];
+            if (tid == 0) {
+                rec->n = n;
+                rec->lo = clip_lo;
+                rec->hi = clip_hi;
+                rec->state = 1;
+            }
+            return;
+        }
         fp_refine_tail<BLOCK>(A, r, state, ns, W, n, cpts, ev, zz, tmp, reinterpret_cast<unsigned char *>(Mt), hist, sh, nseg,
                               [&](int sbs, int, const double *&sc_t, const float *&sg_t) {
                                   sc_t = scores + sbs;   // the adapter pass's score curve and clipped samples are still here
@@ -1425,6 +1448,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
         }
         for (int i = tid; i < nt; i += BLOCK) t_sig[i] = __builtin_amdgcn_fmed3f(src[sbs + i], lo, hi);
         __syncthreads();
+        if (A.stop_phase == 1) return false;
         // windowed t-statistic of the tail (_c_segmentation.pyx:124-161; fp_process_read's operations, both windows per
         // position instead of a staged tile: the tail is a thousand positions)
         const double Wd = (double)W;
@@ -1452,6 +1476,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
             t_scores[pos] = sc;
         }
         __syncthreads();
+        if (A.stop_phase == 2) return false;
         sc_t = t_scores;
         sg_t = t_sig;
         return true;
@@ -1469,6 +1494,7 @@ static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
         static const bool old_match = getenv("WDX_REFINE_MATCH_OLD") != nullptr;
+        if (getenv("WDX_TAIL_STOP")) A.stop_phase = atoi(getenv("WDX_TAIL_STOP"));
         if (old_match) hipLaunchKernelGGL((fingerprint_refine_match_kernel<128>), dim3((unsigned)n), dim3(128), lds_m, stream, A);
         else if (int rc = launch_refine_match_wave(A, n, stream)) return rc;
         hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
@@ -1534,10 +1560,10 @@ static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream, int64_t *n
 
 template <int BLOCK>
 static int launch_fp_list(const FpArgs &A, size_t lds, const unsigned *count, const int32_t *list,
-                          hipStream_t stream) {
+                          hipStream_t stream, int max_grid = 2048) {
     static LdsAttr attr;
     if (int rc = attr.ensure(fingerprint_list_kernel<BLOCK>, lds)) return rc;
-    const int64_t grid = A.n_reads < 2048 ? A.n_reads : 2048;
+    const int64_t grid = A.n_reads < max_grid ? A.n_reads : max_grid;
     hipLaunchKernelGGL((fingerprint_list_kernel<BLOCK>), dim3((unsigned)grid), dim3(BLOCK), lds, stream,
                        A, count, list);
     WDX_HIP_TRY(hipGetLastError());
@@ -1579,7 +1605,7 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
 }
 
 // eight counters (five used) | one ClipRec per read | five read lists (slow, big0, big1, retry, big2: see launch_fingerprint)
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 36 * (n_reads > 0 ? n_reads : 0); }
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 40 * (n_reads > 0 ? n_reads : 0); }
 
 // The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
@@ -1702,7 +1728,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         if (ovl) capP = capF == 4096 ? 1400 : (capF == 5120 ? 1800 : 2040);  // (3 bytes per peak beside the samples)
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt, ovl);
-        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2
+        unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
         ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 32);
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 32 + 16 * n_reads);
         int32_t *big0 = list + n_reads, *big1 = big0 + n_reads, *retry = big1 + n_reads, *big2 = retry + n_reads;
@@ -1859,10 +1885,22 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         }
         WDX_HIP_TRY(hipGetLastError());
         if (!chain) return WDX_SUCCESS;  // (ablation timing of the main kernel: the lists are left unprocessed)
-        if (rf)  // the refinement branch of the reads a fast kernel segmented; its hand-overs join the slow list
-            if (int rc = launch_refine_tail(A, count, list, stream)) return rc;
-        if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
-                           : launch_fp_list<1024>(A, lds, count, list, stream))
+        if (rf) {
+            // refinement branch: the exact kernel segments the adapters of the slow list's reads and leaves them, like the
+            // fast kernels theirs, to the refinement kernels (reads it cannot hand over it refines in place); barcode
+            // tails beyond the tail kernel's capacity come back on a list of their own for the exact kernel's full form
+            int32_t *back = big2 + n_reads;
+            A.refine_record = 1;
+            if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
+                               : launch_fp_list<1024>(A, lds, count, list, stream))
+                return rc;
+            A.refine_record = 0;
+            if (int rc = launch_refine_tail(A, count + 5, back, stream)) return rc;
+            if (int rc = small ? launch_fp_list<512>(A, lds, count + 5, back, stream)
+                               : launch_fp_list<1024>(A, lds, count + 5, back, stream))
+                return rc;
+        } else if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
+                                  : launch_fp_list<1024>(A, lds, count, list, stream))
             return rc;
         if (with_huge)
             if (int rc = launch_fp_big(A, cap, count, list, stream)) return rc;

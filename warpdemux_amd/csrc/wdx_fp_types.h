@@ -59,6 +59,8 @@ struct FpArgs {
     double *big_scores;  // kBigSlots x kBigCap doubles: score curves of windows beyond the LDS capacity (nullable)
     int defer_big;       // 1: a window beyond `cap` is left to fingerprint_big_kernel (no status written here)
     int no_list;         // WDX_OPT_EXACT_NO_PEAK_LIST: fp_segment in position space only (diagnostic)
+    int refine_record;   // exact kernel, refinement branch: 1 = leave a RefineRec for the refinement kernels where the read
+                         // allows it (no NaN in the window, configured window width) instead of refining in place
 };
 
 // Clip bounds of one read, computed ahead of the fast kernels' launch chain by clip_bounds_kernel (one wave per read,
