@@ -441,7 +441,8 @@ __device__ __forceinline__ int block_excl_scan(int v, FpShared &sh, int &total) 
 template <int BLOCK>
 __device__ int fp_segment(const double *scores, unsigned char *state, const int ns, const int d_eff, const int W,
                           const int E, const bool accept_less, const float *sig, const int n_end, int *cpts, double *ev,
-                          unsigned *hist, FpShared &sh, int &nseg, int &nms_iters, const bool no_list = false) {
+                          unsigned *hist, FpShared &sh, int &nseg, int &nms_iters, const bool no_list = false,
+                          const bool exact_sums = false) {
     const int tid = threadIdx.x;
     // ---- P3: find_peaks(scores, distance=d_eff) ----------------------------------
     for (int i = tid; i < ns; i += BLOCK) state[i] = ST_NONE;
@@ -489,7 +490,53 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
         }
         __syncthreads();
         // greedy suppression by priority (see the position-space form below for the rule): a peak's rivals are the list
-        // neighbours closer than d_eff; ties -> the LATER peak outranks
+        // neighbours closer than d_eff; ties -> the LATER peak outranks.  Only the rivals that OUTRANK a peak decide
+        // about it (a lower-ranked rival stays undecided for as long as this peak is), and which those are never
+        // changes: each thread finds them once -- a 16-bit mask over the up to eight list neighbours on either side
+        // (local maxima are at least two positions apart, d_eff <= 17) -- and the rounds only re-read their state bytes.
+        constexpr int kNmsPer = 4;   // list entries per thread held in registers
+        if (d_eff <= 17 && np <= kNmsPer * BLOCK) {
+            unsigned hp[kNmsPer];
+            bool und[kNmsPer];
+#pragma unroll
+            for (int m = 0; m < kNmsPer; ++m) {
+                const int k = tid + m * BLOCK;
+                hp[m] = 0;
+                und[m] = k < np;
+                if (k < np) {
+                    const int p = lpos[k];
+                    const double s = scores[p];
+                    for (int q = k - 1; q >= 0 && p - (int)lpos[q] < d_eff; --q)
+                        if (scores[lpos[q]] > s) hp[m] |= 1u << (q - k + 8);
+                    for (int q = k + 1; q < np && (int)lpos[q] - p < d_eff; ++q) {
+                        const double sq = scores[lpos[q]];
+                        if (sq > s || sq == s) hp[m] |= 1u << (q - k + 7);
+                    }
+                }
+            }
+            for (;;) {
+                int pending = 0;
+#pragma unroll
+                for (int m = 0; m < kNmsPer; ++m) {
+                    if (!und[m]) continue;
+                    const int k = tid + m * BLOCK;
+                    bool kept_near = false, wait = false;
+                    unsigned mask = hp[m];
+                    while (mask) {
+                        const int b = __ffs((int)mask) - 1;
+                        mask &= mask - 1;
+                        const unsigned char st = lst[k + (b < 8 ? b - 8 : b - 7)];
+                        kept_near |= st == ST_KEPT;
+                        wait |= st == ST_UNDECIDED;
+                    }
+                    if (kept_near) { lst[k] = ST_DROPPED; und[m] = false; }
+                    else if (!wait) { lst[k] = ST_KEPT; und[m] = false; }
+                    else pending = 1;
+                }
+                ++nms_iters;
+                if (!__syncthreads_or(pending)) break;
+            }
+        } else
         for (;;) {
             int pending = 0;
             for (int k = tid; k < np; k += BLOCK) {
@@ -538,6 +585,35 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
             __syncthreads();
             for (int k = tid; k < np; k += BLOCK)
                 if (lst[k] == ST_KEPT) lst[k] = ST_SELECTED;
+        } else if ((int)nk <= kSegCap) {
+            // few survivors (a barcode tail: ~100): their keys go, in list order, to a dense array and every survivor
+            // counts the ones that outrank it (larger score; equal score and later) -- one pass instead of the seven
+            // digit passes of the radix select below
+            nsel = E;
+            unsigned long long *dk = reinterpret_cast<unsigned long long *>(ev);   // (free until P6)
+            unsigned short *dmap = reinterpret_cast<unsigned short *>(hist);
+            const int c2 = (np + BLOCK - 1) / BLOCK;
+            const int k0 = tid * c2, k1 = min(np, k0 + c2);
+            int local = 0;
+            for (int k = k0; k < k1; ++k) local += lst[k] == ST_KEPT;
+            int tot;
+            int o = block_excl_scan<BLOCK>(local, sh, tot);
+            for (int k = k0; k < k1; ++k)
+                if (lst[k] == ST_KEPT) {
+                    dk[o] = (unsigned long long)__double_as_longlong(scores[lpos[k]]);
+                    dmap[o] = (unsigned short)k;
+                    ++o;
+                }
+            __syncthreads();
+            for (int t = tid; t < (int)nk; t += BLOCK) {
+                const unsigned long long key = dk[t];
+                int rank = 0;
+                for (int j = 0; j < (int)nk; ++j) {
+                    const unsigned long long kj = dk[j];
+                    rank += (kj > key) || (kj == key && j > t);
+                }
+                if (rank < E) lst[dmap[t]] = ST_SELECTED;
+            }
         } else {
             nsel = E;
             auto keyfn = [&](int k, unsigned long long &key) {
@@ -719,6 +795,25 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
     nseg = nsel + 1;
 
     // ---- P6: event means (_c_segmentation.pyx:41-53), sequential float64 sums ------------------------
+    // exact_sums (the caller's promise: every partial sum of the samples is exactly representable in float64 -- positive
+    // float32 samples within a factor 2^16 of each other): the sum does not depend on its order, eight lanes share a segment
+    if (exact_sums) {
+        const int j = tid & 7;
+        for (int s0 = 0; s0 < nseg; s0 += BLOCK / 8) {   // block-uniform trip count: the shuffles see whole waves
+            const int s = s0 + (tid >> 3);
+            double sum = 0.0;
+            int b = 0, e = 1;
+            if (s < nseg) {
+                b = cpts[s];
+                e = cpts[s + 1];
+                for (int i = b + j; i < e; i += 8) sum += (double)sig[i];
+            }
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 1);
+            if (s < nseg && j == 0) ev[s] = sum / (double)(e - b);
+        }
+    } else
     for (int s = tid; s < nseg; s += BLOCK) {
         const int b = cpts[s], e = cpts[s + 1];
         double sum = 0.0;
@@ -895,7 +990,8 @@ __device__ bool fp_refine_match(const FpArgs &A, const int64_t r, const int *cpt
 
 template <int BLOCK, class Prep>
 __device__ void fp_refine_finish(const FpArgs &A, const int64_t r, const RefineMatch &M, unsigned char *state, const int ns,
-                                 const int n, int *cpts, double *zz, unsigned *hist, FpShared &sh, Prep prep) {
+                                 const int n, int *cpts, double *zz, unsigned *hist, FpShared &sh, Prep prep,
+                                 const bool exact_sums = false) {
     const int tid = threadIdx.x;
     const wdx_seg_params &P = A.p;
     const RefineDev &R = A.rf;
@@ -938,7 +1034,7 @@ __device__ void fp_refine_finish(const FpArgs &A, const int64_t r, const RefineM
             return;
         }
         const int st = fp_segment<BLOCK>(sc_t, state, ns2, P.min_obs_per_base, P.running_stat_width, R.E2, false,
-                                         sg_t, n_end2, cpts, zz, hist, sh, nseg2, it2, A.no_list != 0);
+                                         sg_t, n_end2, cpts, zz, hist, sh, nseg2, it2, A.no_list != 0, exact_sums);
         if (st != WDX_READ_OK) {
             finish(st, false);
             return;
@@ -1480,7 +1576,7 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
         sc_t = t_scores;
         sg_t = t_sig;
         return true;
-    });
+    }, lo > 0.f && hi <= lo * 65536.f);   // (clipped samples in [lo, hi], at most kTailCap of them: their float64 sums are exact)
 }
 
 #ifndef WDX_DEV_KERNELS_ONLY  // (development: a TU that instantiates single kernels includes this file with the macro set)
