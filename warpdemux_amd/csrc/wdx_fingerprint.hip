@@ -1455,57 +1455,59 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_big_kernel(FpArgs A, const 
     }
 }
 
-// The refinement branch behind the FAST kernels (round 3): a fast kernel segments the adapter (RefineRec) and two
-// kernels do everything after it with fp_refine_match / fp_refine_finish, the exact kernel's own code:
-//   fingerprint_refine_match_kernel  adapter statistics, subsequence DP, back-trace.  Pure latency (207 fronts of a DP
-//                                    with <= 97 active threads, single-thread sums and walk): 128 threads and ~17 KB
-//                                    of LDS per read, so that many reads are resident (the one-kernel form at 36 KB
-//                                    was 1.8x slower at half its occupancy);
+// The refinement branch behind the FAST kernels (round 3; the match as a kernel of wave-sized workgroups and the exact
+// kernel's hand-over since round 4): a fast kernel -- or the exact kernel, for a read of the slow list it can hand over --
+// segments the adapter and leaves a RefineRec; two kernels do everything after it, bit for bit what fp_refine_match /
+// fp_refine_finish (the exact kernel's own code) do:
+//   fingerprint_refine_match_wave_kernel  (wdx_refine_match.hip) adapter statistics, subsequence DP, back-trace: one
+//                                    wave per three reads;
 //   fingerprint_refine_tail_kernel   the barcode's own segmentation: loads ONLY the samples from sig_barcode_start on,
 //                                    re-clips them with the recorded bounds (the same v_med3_f32 on the same values),
-//                                    computes their t-scores with the exact kernel's operations and segments them.
-// A barcode tail beyond kTailCap samples is handed to the exact kernel, which runs after these two.
+//                                    computes their t-scores with the exact kernel's operations (every window's
+//                                    statistics once, tiles of 256 window starts) and segments them (fp_segment).
+// A barcode tail beyond kTailCap samples goes back to the exact kernel, which then refines the read in place.
 constexpr int kTailCap = 2048;
-constexpr int kMatchScratch = 3 * (kRefineMaxQuery + 1) * 16 + kRefineMaxQuery * ((kRefineMaxSeries + 15) / 16) * 4;
-static size_t refine_match_lds_bytes() {
-    size_t b = (size_t)kSegCap * 8 * 3 + sizeof(FpShared) + (size_t)(kSegCap + 1) * 4;
-    b = (b + 15) & ~(size_t)15;
-    return (b + kMatchScratch + 15) & ~(size_t)15;
-}
+// LDS of fingerprint_refine_tail_kernel<256>: FpShared | cpts | U | scores | samples, where U holds the event means, the
+// select's histogram and the peak-state bytes of the segmentation and, before it, the window statistics of one t-score tile
+constexpr int kTailBlock = 256;
+constexpr size_t kTailU = ((size_t)kSegCap * 8 + 256 * 4 + kTailCap) > (size_t)kTailBlock * 16
+                              ? ((size_t)kSegCap * 8 + 256 * 4 + kTailCap) : (size_t)kTailBlock * 16;
+static_assert(kTailU % 16 == 0 && (kSegCap * 8) % 16 == 0, "alignment of the regions inside U");
 static size_t refine_tail_lds_bytes() {
-    size_t b = (size_t)kSegCap * 8 + sizeof(FpShared) + 256 * 4 + (size_t)(kSegCap + 1) * 4;
+    size_t b = sizeof(FpShared) + (size_t)(kSegCap + 1) * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)(kTailCap + 64) * 4 + (size_t)kTailCap * 8 + (size_t)kTailCap;
+    b += kTailU + (size_t)kTailCap * 8 + (size_t)(kTailCap + 64) * 4;
     return (b + 15) & ~(size_t)15;
 }
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void fingerprint_refine_match_kernel(FpArgs A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int64_t r = A.block_base + blockIdx.x;
-    if (r >= A.n_reads) return;
-    RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
-    if (rec->state != 1) return;  // not segmented by a fast kernel: the exact kernel takes (or has reported) this read
-    double *ev = reinterpret_cast<double *>(smem);
-    double *zz = ev + kSegCap, *tmp = zz + kSegCap;
-    FpShared &sh = *reinterpret_cast<FpShared *>(tmp + kSegCap);
-    int *cpts = reinterpret_cast<int *>(&sh + 1);
-    unsigned char *scratch = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
-    const int nseg = A.p.num_events + 1;
-    for (int s = tid; s < nseg; s += BLOCK) ev[s] = rec->ev[s];
-    for (int s = tid; s <= nseg; s += BLOCK) cpts[s] = rec->cpts[s];
-    __syncthreads();
-    RefineMatch M;
-    const bool go = fp_refine_match<BLOCK>(A, r, cpts, ev, zz, tmp, scratch, sh, nseg, M);
-    if (tid == 0) {
-        if (go) {
-            static_assert(sizeof(RefineMatch) == 64, "RefineRec::m");
-            memcpy(rec->m, &M, sizeof(M));
+// mean and sum of squared deviations of the W samples from x on (_c_segmentation.pyx:124-161; fp_process_read's
+// operations in its order).  WT > 0: the configured width known at compile time (loads and conversions once)
+template <int WT>
+__device__ __forceinline__ void window_stats(const float *x, const int W, double &m, double &v) {
+    if constexpr (WT > 0) {
+        double xs[WT];
+#pragma unroll
+        for (int k = 0; k < WT; ++k) xs[k] = (double)x[k];
+        m = 0.0;
+#pragma unroll
+        for (int k = 0; k < WT; ++k) m += xs[k];
+        m /= (double)WT;
+        v = 0.0;
+#pragma unroll
+        for (int k = 0; k < WT; ++k) {
+            const double df = xs[k] - m;
+            v += df * df;
         }
-        rec->state = go ? 3 : 4;
+    } else {
+        m = 0.0;
+        for (int k = 0; k < W; ++k) m += (double)x[k];
+        m /= (double)W;
+        v = 0.0;
+        for (int k = 0; k < W; ++k) {
+            const double df = (double)x[k] - m;
+            v += df * df;
+        }
     }
 }
-
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A, unsigned *slow_count, int32_t *slow_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1515,14 +1517,16 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
     RefineRec *rec = reinterpret_cast<RefineRec *>(A.rf.ws) + r;
     if (rec->state != 3) return;
     const wdx_seg_params &P = A.p;
-    double *zz = reinterpret_cast<double *>(smem);
-    FpShared &sh = *reinterpret_cast<FpShared *>(zz + kSegCap);
-    unsigned *hist = reinterpret_cast<unsigned *>(&sh + 1);
-    int *cpts = reinterpret_cast<int *>(hist + 256);
-    unsigned char *T = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
-    double *t_scores = reinterpret_cast<double *>(T);                      // kTailCap
-    float *t_sig = reinterpret_cast<float *>(t_scores + kTailCap);         // kTailCap + 64
-    unsigned char *state = reinterpret_cast<unsigned char *>(t_sig + kTailCap + 64);  // kTailCap
+    static_assert(BLOCK == kTailBlock, "refine_tail_lds_bytes");
+    FpShared &sh = *reinterpret_cast<FpShared *>(smem);
+    int *cpts = reinterpret_cast<int *>(&sh + 1);
+    unsigned char *U = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(cpts + kSegCap + 1) + 15) & ~(uintptr_t)15);
+    double *zz = reinterpret_cast<double *>(U);                                  // kSegCap
+    unsigned *hist = reinterpret_cast<unsigned *>(zz + kSegCap);                 // 256
+    unsigned char *state = reinterpret_cast<unsigned char *>(hist + 256);        // kTailCap
+    double *Mt = reinterpret_cast<double *>(U), *Vt = Mt + BLOCK;                // one tile's window statistics (before these)
+    double *t_scores = reinterpret_cast<double *>(U + kTailU);                   // kTailCap
+    float *t_sig = reinterpret_cast<float *>(t_scores + kTailCap);               // kTailCap + 64
     RefineMatch M;
     memcpy(&M, rec->m, sizeof(M));
     const int n = rec->n, W = P.running_stat_width;
@@ -1544,35 +1548,34 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
         }
         for (int i = tid; i < nt; i += BLOCK) t_sig[i] = __builtin_amdgcn_fmed3f(src[sbs + i], lo, hi);
         __syncthreads();
-        if (A.stop_phase == 1) return false;
-        // windowed t-statistic of the tail (_c_segmentation.pyx:124-161; fp_process_read's operations, both windows per
-        // position instead of a staged tile: the tail is a thousand positions)
-        const double Wd = (double)W;
-        for (int pos = tid; pos < ns2; pos += BLOCK) {
-            double mv[2], vv[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q = pos + h * W;
-                double m = 0.0;
-                for (int k = 0; k < W; ++k) m += (double)t_sig[q + k];
-                m /= Wd;
-                double v = 0.0;
-                for (int k = 0; k < W; ++k) {
-                    const double df = (double)t_sig[q + k] - m;
-                    v += df * df;
-                }
-                mv[h] = m;
-                vv[h] = v;
+        // windowed t-statistic of the tail (_c_segmentation.pyx:124-161; fp_process_read's operations): tiles of BLOCK
+        // window starts -- every window's mean and squared deviations once, one thread each -- then the scores of the
+        // BLOCK - W positions whose two windows the tile holds
+        const int nwin = ns2 > 0 ? ns2 + W : 0;   // window starts 0 .. ns2 + W - 1 (the last one ends at sample nt - 1)
+        const int TP = BLOCK - W;                 // W <= kMaxW = 64 < BLOCK
+        for (int t0 = 0; t0 < ns2; t0 += TP) {
+            const int q = t0 + tid;
+            if (q < nwin) {
+                double m, v;
+                if (W == 18) window_stats<18>(t_sig + q, W, m, v);
+                else if (W == 12) window_stats<12>(t_sig + q, W, m, v);
+                else window_stats<0>(t_sig + q, W, m, v);
+                Mt[tid] = m;
+                Vt[tid] = v;
             }
-            const double vs = vv[0] + vv[1];
-            double sc;
-            if (vs == 0) sc = 0.0;
-            else if (mv[0] > mv[1]) sc = (mv[0] - mv[1]) / sqrt(vs);
-            else sc = (mv[1] - mv[0]) / sqrt(vs);
-            t_scores[pos] = sc;
+            __syncthreads();
+            const int pos = t0 + tid;
+            if (tid < TP && pos < ns2) {
+                const double m1 = Mt[tid], m2 = Mt[tid + W];
+                const double vs = Vt[tid] + Vt[tid + W];
+                double sc;
+                if (vs == 0) sc = 0.0;
+                else if (m1 > m2) sc = (m1 - m2) / sqrt(vs);
+                else sc = (m2 - m1) / sqrt(vs);
+                t_scores[pos] = sc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (A.stop_phase == 2) return false;
         sc_t = t_scores;
         sg_t = t_sig;
         return true;
@@ -1581,18 +1584,14 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A
 
 #ifndef WDX_DEV_KERNELS_ONLY  // (development: a TU that instantiates single kernels includes this file with the macro set)
 static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list, hipStream_t stream) {
-    static LdsAttr attr_m, attr_t;
-    const size_t lds_m = refine_match_lds_bytes(), lds_t = refine_tail_lds_bytes();
-    if (int rc = attr_m.ensure(fingerprint_refine_match_kernel<128>, lds_m)) return rc;
+    static LdsAttr attr_t;
+    const size_t lds_t = refine_tail_lds_bytes();
     if (int rc = attr_t.ensure(fingerprint_refine_tail_kernel<256>, lds_t)) return rc;
     const int64_t slice = 1 << 22;
     for (int64_t base = 0; base < A.n_reads; base += slice) {
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
-        static const bool old_match = getenv("WDX_REFINE_MATCH_OLD") != nullptr;
-        if (getenv("WDX_TAIL_STOP")) A.stop_phase = atoi(getenv("WDX_TAIL_STOP"));
-        if (old_match) hipLaunchKernelGGL((fingerprint_refine_match_kernel<128>), dim3((unsigned)n), dim3(128), lds_m, stream, A);
-        else if (int rc = launch_refine_match_wave(A, n, stream)) return rc;
+        if (int rc = launch_refine_match_wave(A, n, stream)) return rc;
         hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
                            slow_list);
     }
@@ -1992,8 +1991,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                 return rc;
             A.refine_record = 0;
             if (int rc = launch_refine_tail(A, count + 5, back, stream)) return rc;
-            if (int rc = small ? launch_fp_list<512>(A, lds, count + 5, back, stream)
-                               : launch_fp_list<1024>(A, lds, count + 5, back, stream))
+            // (a grid-stride kernel: one workgroup per CU serves this list, which is empty unless barcodes are very long --
+            // 2048 workgroups of ~100 KB that only find it empty cost 70 us)
+            if (int rc = small ? launch_fp_list<512>(A, lds, count + 5, back, stream, 256)
+                               : launch_fp_list<1024>(A, lds, count + 5, back, stream, 256))
                 return rc;
         } else if (int rc = small ? launch_fp_list<512>(A, lds, count, list, stream)
                                   : launch_fp_list<1024>(A, lds, count, list, stream))
