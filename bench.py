@@ -622,10 +622,16 @@ def secondary_regimes(device):
                         np.array_equal(gdev[0][:nr].cpu().numpy().view(np.uint64), fr.fpt.view(np.uint64)))
         del dmb, gdev
         engr.close()
+        # algorithmic bytes per read: the adapter window once + the barcode tail once more (the second segmentation) +
+        # fingerprint, statistics, indices and status out
+        bpr_r = 4.0 * float((aer - asr + 200).mean()) + 4.0 * 1100 + 8.0 * 25 + 8.0 * 6 + 12.0 + 4.0
+        rps_r = nr * rep / (sum(wl) / len(wl))
         trip["trna_refine_flow"] = {
             "reads_per_s": nr / (ms_.value / 3 * 1e-3), "ms": ms_.value / 3, "reads": nr, "timing": "HIP events around the fingerprint launches (host copies excluded)",
-            "device_resident": {"reads": nr * rep, "reads_per_s": nr * rep / (sum(wl) / len(wl)), "ms": 1e3 * sum(wl) / len(wl),
-                                "same_bits_as_host_call": dev_same},
+            "device_resident": {"reads": nr * rep, "reads_per_s": rps_r, "ms": 1e3 * sum(wl) / len(wl),
+                                "same_bits_as_host_call": dev_same,
+                                "roofline": {"bound": "hbm", "bytes_per_read": bpr_r, "achieved": rps_r * bpr_r / 1e9, "unit": "GB/s",
+                                             "peak": HBM_PEAK_GBS, "frac": rps_r * bpr_r / 1e9 / HBM_PEAK_GBS}},
             "ok_reads": int((fr.status == 0).sum()), "consensus_outliers": int((fr.status == 6).sum()), "parity_reads": ns_,
             "parity": bool(dev_same and np.array_equal(fr.status[:ns_], ostat) and np.array_equal(fr.fpt[:ns_][okt].view(np.uint64), ofp[okt].view(np.uint64))
                            and np.array_equal(fr.refine_idx[:ns_][okt], oidx[okt]))}
