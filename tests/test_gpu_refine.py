@@ -215,6 +215,46 @@ def test_refinement_behind_the_fast_kernels_matches_the_exact_kernel_and_the_ora
     assert (status == 0).sum() > 250 and (status == 6).sum() > 50 and status[3] == 1
 
 
+@pytest.mark.parametrize("nq,E,psi", [(5, 40, (0, 0, 0, 0)), (33, 64, (3, 0, 10, 0)), (84, 120, (5, 0, 40, 0)), (96, 125, (7, 0, 59, 0)), (96, 127, (7, 0, 59, 0)),
+                                       (50, 126, (0, 0, 120, 0))])
+def test_refinement_wave_match_kernel_on_ties_and_odd_shapes(nq, E, psi):
+    """fingerprint_refine_match_wave_kernel away from the tRNA shape: query lengths that are no multiple of its four rows
+    per lane (two or three reads per wave), series shorter and longer than a wave, relaxations from none to nearly the
+    whole series -- on signals whose levels and noise sit on a coarse grid, so that event means repeat, the DP's costs tie
+    exactly and the direction codes / the arg-min of the last row are decided by the first-minimum rules.  A batch large
+    enough for the launch chain (fast kernels + refinement kernels) against the oracle, bit for bit."""
+    rng = np.random.default_rng(nq * 1000 + E)
+    query = np.round(rng.normal(0, 1, nq) * 2) / 2
+    n = 2304
+    rows = []
+    for i in range(n):
+        n_lead = int(rng.integers(0, max(1, E - nq - 8)))
+        n_tail = 28
+        body = query if i % 3 else np.round(rng.normal(0, 1, nq) * 2) / 2
+        lv = np.concatenate([np.round(rng.normal(0, 1, n_lead) * 2) / 2, body, np.round(rng.normal(0, 1, n_tail) * 2) / 2]) * 12.0 + 85.0
+        dw = rng.integers(20, 44, lv.size)
+        noise = np.round(rng.normal(0, 1.5, int(dw.sum())) * 4) / 4
+        rows.append((np.repeat(lv, dw) + noise).astype(np.float32)[:6000])
+    stride = max(r.size for r in rows)
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, : r.size] = r
+    a_s = np.full(n, 50, dtype=np.int32)
+    a_e = np.array([r.size - 50 for r in rows], dtype=np.int32)
+    seg = dict(padding=50, min_obs_per_base=9, running_stat_width=18, num_events=E)
+    ref = dict(subseq_norm="median" if nq % 2 else "mean", penalty=1.5, psi=psi, ub_start=E, lb_end=0, ub_end=E + 1,
+               barcode_segm_events=20, barcode_keep_events=20)
+    fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=20, **seg),
+                                           sig_proc.RefineParams(query=query, **ref))
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=20, **seg),
+                                                                  orc.RefineParams(query=query, **ref))
+    assert np.array_equal(fb.status, status), np.flatnonzero(fb.status != status)[:10]
+    good, rep = status == 0, (status == 0) | (status == 6)
+    assert good.sum() > n // 4, np.bincount(status, minlength=8)
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good])
+    assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep])
+
+
 def test_refinement_device_resident_entry_point(golden_dir):
     """wdx_fingerprint_refine_dev (DemuxEngine.fingerprint_refine): device tensors in and out, same bits as the host
     batch call, minibatch and packed layouts."""
