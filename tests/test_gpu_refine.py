@@ -183,7 +183,11 @@ def test_refinement_behind_the_fast_kernels_matches_the_exact_kernel_and_the_ora
         lv = list(rng.normal(0, 1, n_lead)) + list(consensus if emb else rng.normal(0, 1, consensus.size)) + list(rng.normal(0, 1, n_tail))
         lv = np.array(lv) * 12.0 + 85.0
         dw = rng.integers(12, 50, lv.size)
-        rows.append((np.repeat(lv, dw) + rng.normal(0, rng.uniform(0.8, 2.5), int(dw.sum()))).astype(np.float32)[:8100])
+        x = (np.repeat(lv, dw) + rng.normal(0, rng.uniform(0.8, 2.5), int(dw.sum()))).astype(np.float32)[:8100]
+        if i % 50 == 7:
+            x = x[:int(rng.integers(1900, 2150))]     # a window too short for the configured width: the parameters shrink
+                                                      # (sig_proc.py:526-533), the exact kernel keeps the read to itself
+        rows.append(x)
     stride = max(r.size for r in rows)
     mb = np.full((n, stride), np.nan, dtype=np.float32)
     for i, r in enumerate(rows):
@@ -193,6 +197,7 @@ def test_refinement_behind_the_fast_kernels_matches_the_exact_kernel_and_the_ora
     ok = np.ones(n, dtype=np.uint8)
     ok[3] = 0
     mb[5, 1500:1503] = np.nan
+    mb[6, 3000] = np.inf                              # (the clip bounds become NaN: every sample NaN, no hand-over)
     seg = dict(min_obs_per_base=9, running_stat_width=18, num_events=120)
     ref = dict(barcode_segm_events=25, barcode_keep_events=25)
     hp, hr = sig_proc.SegParams(barcode_num_events=25, **seg), sig_proc.RefineParams(query=consensus, **ref)
