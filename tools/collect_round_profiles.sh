@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r04b}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -19,6 +19,9 @@ python3 tools/phase_counters.py 262144 > gpurun_out/${TAG}_phase_counters.txt 2>
 python3 tools/profile_fingerprint.py 16384 1 1000000 > gpurun_out/${TAG}_fast_kernel_phase_shares.txt 2>&1
 python3 tools/long_window_bench.py 110 15 30 8192 > gpurun_out/${TAG}_window_lengths.txt 2>&1
 python3 tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine.txt 2>&1
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} bash tools/dev/rfstats.sh > gpurun_out/${TAG}_refine_kernel_trace.txt 2>&1
+python3 tools/pmc_kernel.py refine_tail_kernel,refine_match_wave,fingerprint_list_kernel -- python3 $PWD/tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine_sq_counters.txt 2>&1
+python3 bench.py --leg shipped_model_e2e > gpurun_out/${TAG}_shipped_model_e2e.json 2> /dev/null
 for t in "110 6 12" "110 15 30" "120 9 18"; do python3 tools/profile_exact.py $t 65536 >> gpurun_out/${TAG}_exact_kernel_triples.txt 2>&1; done
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_traffic gpurun_out/${TAG}_sq gpurun_out/phase_pmc
 ls -la gpurun_out | grep ${TAG}
