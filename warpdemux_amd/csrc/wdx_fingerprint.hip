@@ -840,10 +840,6 @@ __device__ int fp_segment(const double *scores, unsigned char *state, const int 
 // different LDS needs (the match is pure latency and wants many resident workgroups; the barcode's segmentation
 // needs the tail's samples and scores): fp_refine_match -- adapter statistics, subsequence match, back-trace ->
 // RefineMatch (false: the read has been reported, nothing more to do) -- and fp_refine_finish.
-struct RefineMatch {
-    double mean, sd, ev_med, ev_mad, dt_med, dt_mad;
-    int32_t qs, qe, sbs, pad_;
-};
 template <int BLOCK>
 __device__ bool fp_refine_match(const FpArgs &A, const int64_t r, const int *cpts, double *ev, double *zz, double *tmp,
                                 unsigned char *scratch, FpShared &sh, const int nseg, RefineMatch &M) {
@@ -1466,7 +1462,6 @@ __global__ __launch_bounds__(BLOCK) void fingerprint_big_kernel(FpArgs A, const 
 //                                    computes their t-scores with the exact kernel's operations (every window's
 //                                    statistics once, tiles of 256 window starts) and segments them (fp_segment).
 // A barcode tail beyond kTailCap samples goes back to the exact kernel, which then refines the read in place.
-constexpr int kTailCap = 2048;
 // LDS of fingerprint_refine_tail_kernel<256>: FpShared | cpts | U | scores | samples, where U holds the event means, the
 // select's histogram and the peak-state bytes of the segmentation and, before it, the window statistics of one t-score tile
 constexpr int kTailBlock = 256;
@@ -1478,35 +1473,6 @@ static size_t refine_tail_lds_bytes() {
     b = (b + 15) & ~(size_t)15;
     b += kTailU + (size_t)kTailCap * 8 + (size_t)(kTailCap + 64) * 4;
     return (b + 15) & ~(size_t)15;
-}
-// mean and sum of squared deviations of the W samples from x on (_c_segmentation.pyx:124-161; fp_process_read's
-// operations in its order).  WT > 0: the configured width known at compile time (loads and conversions once)
-template <int WT>
-__device__ __forceinline__ void window_stats(const float *x, const int W, double &m, double &v) {
-    if constexpr (WT > 0) {
-        double xs[WT];
-#pragma unroll
-        for (int k = 0; k < WT; ++k) xs[k] = (double)x[k];
-        m = 0.0;
-#pragma unroll
-        for (int k = 0; k < WT; ++k) m += xs[k];
-        m /= (double)WT;
-        v = 0.0;
-#pragma unroll
-        for (int k = 0; k < WT; ++k) {
-            const double df = xs[k] - m;
-            v += df * df;
-        }
-    } else {
-        m = 0.0;
-        for (int k = 0; k < W; ++k) m += (double)x[k];
-        m /= (double)W;
-        v = 0.0;
-        for (int k = 0; k < W; ++k) {
-            const double df = (double)x[k] - m;
-            v += df * df;
-        }
-    }
 }
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fingerprint_refine_tail_kernel(FpArgs A, unsigned *slow_count, int32_t *slow_list) {
@@ -1592,8 +1558,12 @@ static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
         if (int rc = launch_refine_match_wave(A, n, stream)) return rc;
-        hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
-                           slow_list);
+        if (refine_tail_wave_takes(A)) {
+            if (int rc = launch_refine_tail_wave(A, n, slow_count, slow_list, stream)) return rc;
+        } else {
+            hipLaunchKernelGGL((fingerprint_refine_tail_kernel<256>), dim3((unsigned)n), dim3(256), lds_t, stream, A, slow_count,
+                               slow_list);
+        }
     }
     WDX_HIP_TRY(hipGetLastError());
     return WDX_SUCCESS;
@@ -2008,6 +1978,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u to the 8192-sample list kernel, %u to the "
                             "streaming kernel, %u redone with exact scores, %u on the exact general kernel\n", (long long)n_reads,
                     c[1], c[2], c[4], c[3], c[0]);
+            if (rf)
+                fprintf(stderr, "[wdx] refinement: %u reads back from the tail kernel to the exact kernel (%u for a run of equal scores across a "
+                                "tile's end, %u beyond the peak list)\n", c[5], c[6], c[7]);
             if (ext) {
                 std::vector<ClipRec> h((size_t)n_reads);
                 WDX_HIP_TRY(hipMemcpy(h.data(), clip, sizeof(ClipRec) * (size_t)n_reads, hipMemcpyDeviceToHost));

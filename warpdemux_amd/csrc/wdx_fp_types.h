@@ -32,6 +32,13 @@ struct RefineRec {
     double m[8];           // RefineMatch of the match kernel (bit copy)
 };
 static_assert(sizeof(RefineRec) == 1632, "fingerprint_refine_ws_bytes");
+// what the subsequence match leaves for the barcode's segmentation (RefineRec::m, bit copy)
+struct RefineMatch {
+    double mean, sd, ev_med, ev_mad, dt_med, dt_mad;
+    int32_t qs, qe, sbs, pad_;
+};
+static_assert(sizeof(RefineMatch) == 64, "RefineRec::m");
+constexpr int kTailCap = 2048;        // barcode tails up to this many samples are segmented by the refinement tail kernels
 constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
 constexpr int kRefineMaxSeries = 128;
 
@@ -105,8 +112,42 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
                             hipStream_t stream);
 
+// mean and sum of squared deviations of the W samples from x on (_c_segmentation.pyx:124-161; fp_process_read's
+// operations in its order).  WT > 0: the configured width known at compile time (loads and conversions once)
+template <int WT>
+__device__ __forceinline__ void window_stats(const float *x, const int W, double &m, double &v) {
+    if constexpr (WT > 0) {
+        double xs[WT];
+#pragma unroll
+        for (int k = 0; k < WT; ++k) xs[k] = (double)x[k];
+        m = 0.0;
+#pragma unroll
+        for (int k = 0; k < WT; ++k) m += xs[k];
+        m /= (double)WT;
+        v = 0.0;
+#pragma unroll
+        for (int k = 0; k < WT; ++k) {
+            const double df = xs[k] - m;
+            v += df * df;
+        }
+    } else {
+        m = 0.0;
+        for (int k = 0; k < W; ++k) m += (double)x[k];
+        m /= (double)W;
+        v = 0.0;
+        for (int k = 0; k < W; ++k) {
+            const double df = (double)x[k] - m;
+            v += df * df;
+        }
+    }
+}
+
 // the subsequence match of the consensus refinement for the reads a fast kernel segmented (RefineRec::state == 1), reads
 // block_base .. block_base + n of A: one wave per group of reads (wdx_refine_match.hip)
 int launch_refine_match_wave(FpArgs A, int64_t n, hipStream_t stream);
+// the barcode's own segmentation for the matched reads (RefineRec::state == 3), one wave per read (wdx_refine_tail.hip);
+// false: the parameters are outside what it takes (the workgroup-per-read kernel in wdx_fingerprint.hip serves those)
+bool refine_tail_wave_takes(const FpArgs &A);
+int launch_refine_tail_wave(FpArgs A, int64_t n, unsigned *back_count, int32_t *back_list, hipStream_t stream);
 
 }  // namespace wdx
