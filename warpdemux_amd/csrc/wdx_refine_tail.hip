@@ -33,15 +33,22 @@ enum : unsigned char { S_UNDECIDED = 1, S_KEPT = 2, S_DROPPED = 3, S_SELECTED = 
 
 struct TwLds {
     double Mt[kWin], Vt[kWin];            // window statistics of the tile; later: dense keys of the kept peaks (<= 384)
-    double scl[kWin];                     // scores of the tile's positions t0 - 1 .. (index 0 = position t0 - 1)
-    float sig[kWin + 64 + 8];             // the tile's clipped samples
+    union {
+        double scl[kWin];                 // scores of the tile's positions t0 - 1 .. (index 0 = position t0 - 1)
+        struct {                          // ... and once the peak list is complete:
+            double ev[kSegMax + 1];
+            int cpts[kSegMax + 2];
+        } seg;
+    } a;
+    union {
+        float sig[kWin + 64 + 8];         // the tile's clipped samples
+        unsigned short dmap[kPeakCap];    // ... later: dense index -> list index
+    } b;
     double pk_score[kPeakCap];
     unsigned short pk_pos[kPeakCap];
-    unsigned short dmap[kPeakCap];        // dense index -> list index
     unsigned char pk_st[kPeakCap];
-    int cpts[kSegMax + 2];
-    double ev[kSegMax + 1];
 };
+static_assert(sizeof(TwLds) <= 12 * 1024, "thirteen waves per CU");
 
 __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {   // set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -107,23 +114,29 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
     const int NSC = kWin - W;                 // scored positions per tile: t0 - 1 .. t0 + TP + kLook
     int np = 0;
     bool plateau = false;
+    // (a tile's samples are requested while the tile before it is being scored: index-clamped loads, five per lane)
+    constexpr int kLd = (kWin + 64) / 64;
+    float nxt[kLd];
+    auto request = [&](const int w0) {
+#pragma unroll
+        for (int k = 0; k < kLd; ++k) nxt[k] = src[min(max(w0 + lane + 64 * k, 0), nt - 1)];
+    };
+    if (ns2 > 0) request(-1);
     for (int t0 = 0; t0 < ns2; t0 += TP) {
         const int w0 = t0 - 1;   // first window start / first scored position of the tile (-1: nothing there)
         __syncthreads();         // (the previous tile's readers are done)
 #pragma unroll
-        for (int k = 0; k < (kWin + 64) / 64; ++k) {
-            const int i = w0 + lane + 64 * k;
-            if (i >= 0 && i < nt) S.sig[lane + 64 * k] = __builtin_amdgcn_fmed3f(src[i], lo, hi);
-        }
+        for (int k = 0; k < kLd; ++k) S.b.sig[lane + 64 * k] = __builtin_amdgcn_fmed3f(nxt[k], lo, hi);
         __syncthreads();
+        if (t0 + TP < ns2) request(t0 + TP - 1);
 #pragma unroll
         for (int k = 0; k < kWin / 64; ++k) {
             const int j = lane + 64 * k, q = w0 + j;
             if (q >= 0 && q < nwin) {
                 double m, v;
-                if (W == 18) window_stats<18>(S.sig + j, W, m, v);
-                else if (W == 12) window_stats<12>(S.sig + j, W, m, v);
-                else window_stats<0>(S.sig + j, W, m, v);
+                if (W == 18) window_stats<18>(S.b.sig + j, W, m, v);
+                else if (W == 12) window_stats<12>(S.b.sig + j, W, m, v);
+                else window_stats<0>(S.b.sig + j, W, m, v);
                 S.Mt[j] = m;
                 S.Vt[j] = v;
             }
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
                 if (vs == 0) sc = 0.0;
                 else if (m1 > m2) sc = (m1 - m2) / sqrt(vs);
                 else sc = (m2 - m1) / sqrt(vs);
-                S.scl[j] = sc;
+                S.a.scl[j] = sc;
             }
         }
         __syncthreads();
@@ -153,12 +166,12 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             double s = 0.0;
             int ppos = p;
             if (j <= TP && p >= 1 && p <= ns2 - 2) {
-                s = S.scl[j];
-                if (S.scl[j - 1] < s) {
+                s = S.a.scl[j];
+                if (S.a.scl[j - 1] < s) {
                     int ja = j + 1;
-                    while (ja < NSC && w0 + ja < ns2 - 1 && S.scl[ja] == s) ++ja;
+                    while (ja < NSC && w0 + ja < ns2 - 1 && S.a.scl[ja] == s) ++ja;
                     if (ja >= NSC) plateau = true;
-                    else if (S.scl[ja] < s) {
+                    else if (S.a.scl[ja] < s) {
                         pk = true;
                         ppos = (p + (w0 + ja) - 1) / 2;
                     }
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             if (kept) {
                 const int o = nk + (int)lanes_below(mk);
                 dk[o] = (unsigned long long)__double_as_longlong(S.pk_score[k]);
-                S.dmap[o] = (unsigned short)k;
+                S.b.dmap[o] = (unsigned short)k;
             }
             nk += __popcll(mk);
         }
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             }
             sel = rank < E;
         }
-        if (sel) S.pk_st[S.dmap[t]] = S_SELECTED;
+        if (sel) S.pk_st[S.b.dmap[t]] = S_SELECTED;
     }
     __syncthreads();
     // ---- boundaries 0, peaks + W (ascending), n_end (sig_proc.py:188-196) -----------------------------------------------
@@ -271,12 +284,12 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             const int k = lane + 64 * m;
             const bool sel = k < np && S.pk_st[k] == S_SELECTED;
             const unsigned long long mk = __ballot(sel);
-            if (sel) S.cpts[o + (int)lanes_below(mk)] = (int)S.pk_pos[k] + W;
+            if (sel) S.a.seg.cpts[o + (int)lanes_below(mk)] = (int)S.pk_pos[k] + W;
             o += __popcll(mk);
         }
         if (lane == 0) {
-            S.cpts[0] = 0;
-            S.cpts[nsel + 1] = n_end2;
+            S.a.seg.cpts[0] = 0;
+            S.a.seg.cpts[nsel + 1] = n_end2;
         }
     }
     const int nseg2 = nsel + 1;
@@ -291,21 +304,28 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             double sum = 0.0;
             int b = 0, e = 1;
             if (s < nseg2) {
-                b = S.cpts[s];
-                e = S.cpts[s + 1];
-                for (int i = b + j; i < e; i += 8) sum += (double)__builtin_amdgcn_fmed3f(src[i], lo, hi);
+                b = S.a.seg.cpts[s];
+                e = S.a.seg.cpts[s + 1];
+                for (int i0 = b + j; i0 < e; i0 += 64) {   // eight loads in flight per lane: one memory latency per 64 samples
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = src[min(i0 + 8 * u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (i0 + 8 * u < e) sum += (double)__builtin_amdgcn_fmed3f(x[u], lo, hi);
+                }
             }
             sum += __shfl_xor(sum, 4);
             sum += __shfl_xor(sum, 2);
             sum += __shfl_xor(sum, 1);
-            if (s < nseg2 && j == 0) S.ev[s] = sum / (double)(e - b);
+            if (s < nseg2 && j == 0) S.a.seg.ev[s] = sum / (double)(e - b);
         }
     } else {
         for (int s = lane; s < nseg2; s += 64) {
-            const int b = S.cpts[s], e = S.cpts[s + 1];
+            const int b = S.a.seg.cpts[s], e = S.a.seg.cpts[s + 1];
             double sum = 0.0;
             for (int i = b; i < e; ++i) sum += (double)__builtin_amdgcn_fmed3f(src[i], lo, hi);
-            S.ev[s] = sum / (double)(e - b);
+            S.a.seg.ev[s] = sum / (double)(e - b);
         }
     }
     __syncthreads();
@@ -336,8 +356,8 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
     }
     for (int i = lane; i < K; i += 64) {
         const int s = nseg2 - K + i;
-        if (A.fpt) A.fpt[r * K + i] = (S.ev[s] - shift) / scale;
-        if (A.dwell) A.dwell[r * K + i] = (int64_t)(S.cpts[s + 1] - S.cpts[s]);
+        if (A.fpt) A.fpt[r * K + i] = (S.a.seg.ev[s] - shift) / scale;
+        if (A.dwell) A.dwell[r * K + i] = (int64_t)(S.a.seg.cpts[s + 1] - S.a.seg.cpts[s]);
     }
     if (lane == 0) A.status[r] = WDX_READ_OK;
 }
