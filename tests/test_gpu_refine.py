@@ -260,6 +260,52 @@ def test_refinement_wave_match_kernel_on_ties_and_odd_shapes(nq, E, psi):
     assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep])
 
 
+@pytest.mark.parametrize("w,d", [(12, 6), (18, 9), (30, 15)])
+def test_refinement_tail_wave_kernel_long_noisy_tails_and_hand_backs(golden_dir, w, d):
+    """fingerprint_refine_tail_wave_kernel at the edges of what it takes: barcode tails of 1 700 .. 2 048 samples (its
+    capacity; a sample more and the exact kernel refines the read), tails of nearly white noise whose score curves have
+    about as many local maxima as its peak list holds (400 .. 450 of 512), coarse samples whose clipped stretches make
+    runs of equal scores across tile ends, and the three shipped window widths (12 and 18 unrolled, 30 the
+    general loop).  Against the oracle, bit for bit."""
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]
+    rng = np.random.default_rng(500 + w)
+    n = 360
+    rows = []
+    for i in range(n):
+        n_lead = int(rng.integers(2, 20))
+        head = np.concatenate([rng.normal(0, 1, n_lead), consensus]) * 12.0 + 85.0
+        dwh = rng.integers(2 * d + 2, 4 * d + 8, head.size)
+        x = np.repeat(head, dwh) + rng.normal(0, 1.5, int(dwh.sum()))
+        tail_len = int(rng.integers(1700, 2060))                      # around kTailCap
+        kind = i % 3
+        if kind == 0:      # ordinary events
+            lv = rng.normal(0, 1, tail_len // (3 * d) + 2) * 12.0 + 85.0
+            t = np.repeat(lv, 3 * d)[:tail_len] + rng.normal(0, 1.5, tail_len)
+        elif kind == 1:    # nearly white noise: a local maximum every ~5 positions
+            t = 85.0 + rng.normal(0, 6.0, tail_len)
+        else:              # coarse, heavily clipped
+            t = np.round((85.0 + rng.normal(0, 9.0, tail_len)) / 4.0) * 4.0
+        rows.append(np.concatenate([x, t]).astype(np.float32))
+    stride = max(r.size for r in rows)
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, : r.size] = r
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array([r.size for r in rows], dtype=np.int32)
+    E = 120
+    seg = dict(padding=0, min_obs_per_base=d, running_stat_width=w, num_events=E, outlier_thresh=3.0 if w == 18 else 5.0)
+    ref = dict(barcode_segm_events=60, barcode_keep_events=40, ub_start=E, lb_end=0, ub_end=E + 1, psi=(5, 0, 60, 0))
+    fb = sig_proc.fingerprint_refine_batch(mb, a_s, a_e, sig_proc.SegParams(barcode_num_events=40, **seg),
+                                           sig_proc.RefineParams(query=consensus, **ref))
+    fpt, dwell, stats, idx, status = orc.fingerprint_refine_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=40, **seg),
+                                                                  orc.RefineParams(query=consensus, **ref))
+    assert np.array_equal(fb.status, status), (np.flatnonzero(fb.status != status)[:10], np.bincount(status, minlength=8))
+    good, rep = status == 0, (status == 0) | (status == 6)
+    assert good.sum() > n // 5, np.bincount(status, minlength=8)
+    assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good])
+    assert _same(fb.stats[rep], stats[rep]) and _same(fb.refine_idx[rep], idx[rep])
+
+
 def test_refinement_device_resident_entry_point(golden_dir):
     """wdx_fingerprint_refine_dev (DemuxEngine.fingerprint_refine): device tensors in and out, same bits as the host
     batch call, minibatch and packed layouts."""

@@ -15,7 +15,7 @@
 //   * event means: eight lanes per segment when the sums are provably exact (positive samples within 2^16 of each other),
 //     else one lane per segment in the reference's order; normalize_wrt, outlier filter, outputs.
 // What it does not take goes back to the exact kernel, which refines the read in place (the hand-back list of
-// launch_fingerprint): a run of equal scores that reaches more than kLook positions past a tile's end, more than kPeakCap local maxima, a tail
+// launch_fingerprint): a run of equal scores that reaches more than kLook positions past a tile's end, more than kPeakCap (512) local maxima, a tail
 // beyond kTailCap samples.  Parameters outside its range (refine_tail_wave_takes) keep the workgroup-per-read kernel.
 #include "wdx_fp_types.h"
 #include "wdx_wave.h"
@@ -26,13 +26,13 @@ namespace {
 
 constexpr int kWin = 256;        // window starts per tile (4 per lane)
 constexpr int kLook = 12;        // scored positions past a tile's own: how far a run of equal scores may reach into the next tile
-constexpr int kPeakCap = 384;    // local maxima of a tail (6 per lane); ~ns / 5.6 are typical: 200 for 1 100 positions
+constexpr int kPeakCap = 512;    // local maxima of a tail (8 per lane); ~ns / 5.6 are typical (200 for 1 100 positions), ns / 4.5 happens
 constexpr int kPeakPer = kPeakCap / 64;
 constexpr int kSegMax = 127;     // segments of the barcode (E2 + 1)
 enum : unsigned char { S_UNDECIDED = 1, S_KEPT = 2, S_DROPPED = 3, S_SELECTED = 4 };
 
 struct TwLds {
-    double Mt[kWin], Vt[kWin];            // window statistics of the tile; later: dense keys of the kept peaks (<= 384)
+    double Mt[kWin], Vt[kWin];            // window statistics of the tile; later: dense keys of the kept peaks (<= 512)
     union {
         double scl[kWin];                 // scores of the tile's positions t0 - 1 .. (index 0 = position t0 - 1)
         struct {                          // ... and once the peak list is complete:
@@ -48,7 +48,7 @@ struct TwLds {
     unsigned short pk_pos[kPeakCap];
     unsigned char pk_st[kPeakCap];
 };
-static_assert(sizeof(TwLds) <= 12 * 1024, "thirteen waves per CU");
+static_assert(sizeof(TwLds) <= 13 * 1024 + 256, "twelve waves per CU");
 
 __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {   // set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
