@@ -842,6 +842,48 @@ def test_demux_svm_dev_whole_path_matches_the_chained_calls_and_sklearn(block_ro
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_classes,n_train", [(2, 80), (3, 150), (11, 500), (16, 800)])
+def test_demux_svm_dev_fused_form_over_class_counts(n_classes, n_train):
+    """The fused form of wdx_demux_svm_dev (decision sums in the DTW kernel's epilogue: two chunks per class, k - 1 sums
+    per lane in LDS) from the smallest model (2 classes: one sum) to the largest supported one (16: fifteen), classes
+    with few support vectors included: against the row-block form (1e-12 on probabilities: another summation order)
+    and against the oracle's fingerprints + scikit-learn (1e-5)."""
+    pytest.importorskip("sklearn")
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    svc, Xtr, Xq, label_mapper, thr, m = _svm_case(n_classes, n_train, 8, seed=40 + n_classes, thresholds=True)
+    K = Xtr.shape[1]
+    spec = synth.SynthSpec(n_barcodes=4)
+    n = 1500
+    eng = DemuxEngine(Xtr, 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
+    eng.set_svm(m)
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 7000, n)
+    pf, qf, cf, sf, _, _ = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len)                      # fused
+    pu, qu, cu, su, du, _ = eng.demux_svm(sig, a_s, a_e, offsets=off, max_len=max_len, want_dist=True)     # row blocks
+    torch.cuda.synchronize()
+    status = sf.cpu().numpy()
+    ok = status == 0
+    assert np.array_equal(status, su.cpu().numpy()) and ok.sum() > 0.95 * n
+    pfn, pun = pf.cpu().numpy(), pu.cpu().numpy()
+    np.testing.assert_allclose(pfn[ok], pun[ok], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(pfn[ok].sum(axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(cf.cpu().numpy()[ok], cu.cpu().numpy()[ok], rtol=0, atol=1e-12)
+    srt = np.sort(pun[ok], axis=1)
+    far = ((srt[:, -1] - srt[:, -2]) > 1e-9) & (np.abs(cu.cpu().numpy()[ok] - thr[np.argmax(pun[ok], axis=1)]) > 1e-9)
+    assert np.array_equal(qf.cpu().numpy()[ok][far], qu.cpu().numpy()[ok][far])
+    ns = 300
+    o = off[: ns + 1].cpu().numpy()
+    ofp, _, _, ost = orc.fingerprint_packed(sig[: int(o[-1])].cpu().numpy(), o, a_s[:ns].cpu().numpy(), a_e[:ns].cpu().numpy(),
+                                            orc.SegParams(barcode_num_events=K))
+    oko = ost == 0
+    _, prob_ref, _ = _reference_tail(svc, Xtr, ofp[oko], label_mapper, thr)
+    np.testing.assert_allclose(pfn[:ns][oko], prob_ref, rtol=0, atol=1e-5)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_dtw_svm_predict_errors_and_single_row():
     pytest.importorskip("sklearn")
     svc, Xtr, Xq, label_mapper, thr, m = _svm_case(3, 150, 8, seed=4)
