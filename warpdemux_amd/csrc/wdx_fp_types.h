@@ -112,9 +112,48 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
                             hipStream_t stream);
 
+// sqrt and quotient of the t-score without the range scaling of the compiler's general float64
+// expansions.  The iterations are exactly the ones hipcc emits for sqrt() and '/' on gfx950
+// (v_rsq_f64 / v_rcp_f64 seeds + the same fma chain), so the results are the same bits; what is dropped
+// is v_ldexp / v_div_scale / v_div_fixup / v_cmp_class, which are identities on the fast path's value
+// range: clipped samples are positive float32 (P1), hence a non-zero variance sum lies in
+// [2^-402, 2^261] (squares of float64 differences of float32 values) and |m1 - m2| in {0} U [2^-201, 2^129]
+// -- far inside the unscaled domain (x >= 2^-767 for sqrt; quotient and reciprocal normal for the
+// division).  A zero variance sum is selected away by the caller.
+__device__ __forceinline__ double fast_sqrt_mid(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double fast_div_mid(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = num * r;
+    const double rem = __builtin_fma(-den, q, num);
+    return __builtin_fma(rem, r, q);
+}
+
+// max(x, +0.0) as one raw v_max_f64 (no canonicalising pre-op): NaN -> 0, x >= 0 -> x
+__device__ __forceinline__ double max0_f64(double x) {
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // mean and sum of squared deviations of the W samples from x on (_c_segmentation.pyx:124-161; fp_process_read's
 // operations in its order).  WT > 0: the configured width known at compile time (loads and conversions once)
-template <int WT>
+// FASTM: positive samples (the value range of fast_div_mid): the quotient without the general expansion's range scaling
+template <int WT, bool FASTM = false>
 __device__ __forceinline__ void window_stats(const float *x, const int W, double &m, double &v) {
     if constexpr (WT > 0) {
         double xs[WT];
@@ -123,7 +162,8 @@ __device__ __forceinline__ void window_stats(const float *x, const int W, double
         m = 0.0;
 #pragma unroll
         for (int k = 0; k < WT; ++k) m += xs[k];
-        m /= (double)WT;
+        if constexpr (FASTM) m = fast_div_mid(m, (double)WT);
+        else m /= (double)WT;
         v = 0.0;
 #pragma unroll
         for (int k = 0; k < WT; ++k) {
@@ -133,7 +173,8 @@ __device__ __forceinline__ void window_stats(const float *x, const int W, double
     } else {
         m = 0.0;
         for (int k = 0; k < W; ++k) m += (double)x[k];
-        m /= (double)W;
+        if constexpr (FASTM) m = fast_div_mid(m, (double)W);
+        else m /= (double)W;
         v = 0.0;
         for (int k = 0; k < W; ++k) {
             const double df = (double)x[k] - m;

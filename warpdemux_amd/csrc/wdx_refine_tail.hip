@@ -19,6 +19,7 @@
 // beyond kTailCap samples.  Parameters outside its range (refine_tail_wave_takes) keep the workgroup-per-read kernel.
 #include "wdx_fp_types.h"
 #include "wdx_wave.h"
+#include <type_traits>
 
 namespace wdx {
 
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
         for (int k = 0; k < kLd; ++k) nxt[k] = src[min(max(w0 + lane + 64 * k, 0), nt - 1)];
     };
     if (ns2 > 0) request(-1);
+    auto tiles = [&](auto fast_t) __attribute__((always_inline)) {
+    constexpr bool FASTM = decltype(fast_t)::value;
     for (int t0 = 0; t0 < ns2; t0 += TP) {
         const int w0 = t0 - 1;   // first window start / first scored position of the tile (-1: nothing there)
         __syncthreads();         // (the previous tile's readers are done)
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             const int j = lane + 64 * k, q = w0 + j;
             if (q >= 0 && q < nwin) {
                 double m, v;
-                if (W == 18) window_stats<18>(S.b.sig + j, W, m, v);
-                else if (W == 12) window_stats<12>(S.b.sig + j, W, m, v);
-                else window_stats<0>(S.b.sig + j, W, m, v);
+                if (W == 18) window_stats<18, FASTM>(S.b.sig + j, W, m, v);
+                else if (W == 12) window_stats<12, FASTM>(S.b.sig + j, W, m, v);
+                else window_stats<0, FASTM>(S.b.sig + j, W, m, v);
                 S.Mt[j] = m;
                 S.Vt[j] = v;
             }
@@ -149,9 +152,13 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
                 const double m1 = S.Mt[j], m2 = S.Mt[j + W];
                 const double vs = S.Vt[j] + S.Vt[j + W];
                 double sc;
-                if (vs == 0) sc = 0.0;
-                else if (m1 > m2) sc = (m1 - m2) / sqrt(vs);
-                else sc = (m2 - m1) / sqrt(vs);
+                if constexpr (FASTM) {   // (rsq(0) = inf -> NaN all the way -> v_max_f64(NaN, 0) = 0: the reference's score of two flat windows)
+                    sc = max0_f64(fast_div_mid(fabs(m1 - m2), fast_sqrt_mid(vs)));
+                } else {
+                    if (vs == 0) sc = 0.0;
+                    else if (m1 > m2) sc = (m1 - m2) / sqrt(vs);
+                    else sc = (m2 - m1) / sqrt(vs);
+                }
                 S.a.scl[j] = sc;
             }
         }
@@ -187,6 +194,11 @@ __global__ __launch_bounds__(64) void fingerprint_refine_tail_wave_kernel(FpArgs
             np += __popcll(mk);
         }
     }
+    };
+    // positive clipped samples (every read a fast kernel segmented): the t-score's quotient and root without the range
+    // scaling of the compiler's general float64 expansions -- the same bits (fast_div_mid / fast_sqrt_mid, wdx_fp_types.h)
+    if (lo > 0.f && hi < 3.0e38f) tiles(std::true_type{});
+    else tiles(std::false_type{});
     if (__any(plateau) || np > kPeakCap || d_eff > 17) {
         if (lane == 0) atomicAdd(back_count + (np > kPeakCap ? 2 : 1), 1u);   // (diagnostic counters [6] plateau, [7] list capacity)
         hand_back();
