@@ -143,11 +143,27 @@ def _oracle_minibatch(job):
     return call, status, D, fpt, dwell
 
 
+def gate_chunks(n_reads, max_reads, chunk):
+    """Where the parity gate looks: chunks of `chunk` reads at evenly spaced offsets over the WHOLE shard -- the first
+    and the last chunk always, then the remaining positions in bit-reversed (van der Corput) order, so that a run cut
+    short by its time budget has still looked at both ends and the middle: every launch slice of the pass (a pass over
+    more than 2^23 reads is cut into equal slices with block_base != 0) and the tail are compared, not just the front."""
+    n_reads, chunk = int(n_reads), int(chunk)
+    if n_reads < 2 * chunk:
+        return [(0, n_reads)]
+    k = max(2, min((min(max_reads, n_reads) + chunk - 1) // chunk, n_reads // chunk))
+    starts = [round(i * (n_reads - chunk) / (k - 1)) for i in range(k)]
+    bits = max(1, (k - 1).bit_length())
+    order = sorted(range(k), key=lambda i: (0 if i in (0, k - 1) else 1, int(format(i, "0%db" % bits)[::-1], 2)))
+    return [(starts[i], starts[i] + chunk) for i in order]
+
+
 def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_s, max_reads):
-    """Walks the first reads of the workload in 32 768-read chunks until the time budget or `max_reads`
+    """Walks 32 768-read chunks spread over the whole shard (`gate_chunks`) until the time budget or `max_reads`
     is reached: oracle on all host cores (timed), GPU results of the same reads compared bit for bit --
     status, call, float32 distances, float64 fingerprints and the int64 dwell times (= the change-points).
-    Returns the cpu_baseline object and the parity record."""
+    `res` is the result of the timed pass over the WHOLE shard, so a chunk at read 9.9 M checks what the second
+    launch slice of that pass wrote.  Returns the cpu_baseline object and the parity record."""
     import numpy as np
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -160,13 +176,16 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
     single = None
     bad = {"status": 0, "call": 0, "dist": 0, "fpt": 0, "dwell": 0}
     max_rel = 0.0
+    spans = []
     t_start = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(lambda i: i, range(cores)))  # threads exist before the clock starts
-        while n_done < min(max_reads, n_reads):
+        for lo, hi in gate_chunks(n_reads, max_reads, chunk):
+            if n_done >= min(max_reads, n_reads):
+                break
             if budget_s > 0 and n_done > 0 and (time.perf_counter() - t_start) > budget_s:
                 break
-            lo, hi = n_done, min(n_done + chunk, n_reads, max_reads)
+            hi = min(hi, lo + min(max_reads, n_reads) - n_done)
             o = off[lo:hi + 1].cpu().numpy()
             sig_h = sig[int(o[0]):int(o[-1])].cpu().numpy()
             as_h, ae_h = a_s[lo:hi].cpu().numpy(), a_e[lo:hi].cpu().numpy()
@@ -204,7 +223,8 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
                 rel = np.abs(D[okm].astype(np.float64) - g_dist[okm]) / np.abs(D[okm].astype(np.float64))
             if rel.size:
                 max_rel = max(max_rel, float(np.nanmax(rel)))
-            n_done = hi
+            n_done += hi - lo
+            spans.append((int(lo), int(hi)))
     parity_ok = not any(bad.values())
     cpu = {
         "value": n_done / t_cpu if t_cpu > 0 else None,
@@ -213,7 +233,7 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
         "logical_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": ("first %d reads of the same workload; oracle/wdx_oracle.c (C restatement of sig_proc.py:394-605 + "
+        "sample": ("%d reads of the same workload in 32 768-read chunks spread evenly over the whole shard; oracle/wdx_oracle.c (C restatement of sig_proc.py:394-605 + "
                    "dtaidistance's banded DTW) driven as %d-read minibatches like file_proc.py:418-450, one worker thread "
                    "per host core on shared buffers (no IPC); dtaidistance itself: see `dtaidistance`" % (n_done, mb)),
         "single_core_value": single,
@@ -222,6 +242,8 @@ def cpu_baseline_and_parity(eng, sig, off, a_s, a_e, res, refs, n_reads, budget_
     }
     parity = {
         "reads_checked": n_done,
+        "read_ranges": sorted(spans),      # [lo, hi) of every chunk compared: spans the shard, both ends included
+        "shard_reads": int(n_reads),
         "checked": "status, call (argmin), float32 distances, float64 fingerprints, int64 dwell (change-points): bitwise",
         "mismatching_reads": bad,
         "max_rel_dist_err": max_rel,
@@ -283,6 +305,35 @@ def _oracle_dtw_threads(X, Y, budget_s=3.0, rows_per_job=32):
             outs += list(ex.map(lambda x: orc.dtw_matrix(x, Y, WINDOW, PENALTY), parts))
             done = hi
     return np.concatenate(outs), done
+
+
+def reference_model_parity(device):
+    """The parity half of the shipped-model leg against a GENUINE reference model: fixture g6b holds the numbers of the
+    reference's WDX10_rna004_v1_0.joblib (2 601 x 25 training fingerprints, 11 classes, thresholds) and what the
+    reference's own DTW_SVM.predict (models/dtw_svm.py:54-98) returned for 256 query fingerprints when it was run in
+    the build container (tests/golden/make_golden_svm.py).  The engine's DTW_SVM on the same queries: probabilities
+    within 1e-5, labels identical wherever the reference's margin is not within 1e-4 of a tie or a threshold."""
+    import numpy as np
+
+    from warpdemux_amd.models import DTW_SVM
+
+    path = os.path.join(ROOT, "tests", "golden", "g6b_dtw_svm_wdx10.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    label_mapper = {int(k): int(v) for k, v in zip(g["label_keys"], g["label_vals"])}
+    m = DTW_SVM(g["X_train"], g["n_support"], g["support"], g["dual_coef"], -g["intercept"], g["probA"], g["probB"],
+                label_mapper, g["thresholds"], window=int(g["window"]), penalty=float(g["penalty"]),
+                gamma=float(g["gamma"]), pwr_dist=int(g["pwr_dist"]), block_size=int(g["block_size"]), device=device)
+    pred, prob = m.predict(g["Xq"])
+    err = float(np.abs(prob - g["y_prob"]).max())
+    srt = np.sort(g["y_prob"], axis=1)
+    conf = srt[:, -1] - srt[:, -2]
+    safe = (conf > 1e-4) & (np.abs(conf - g["thresholds"][np.argmax(g["y_prob"], axis=1)]) > 1e-4)
+    same = bool(np.array_equal(pred[safe], g["y_pred"][safe]))
+    return {"model": "WDX10_rna004_v1_0 (reference model file; fixture g6b = the reference's DTW_SVM.predict run on it)",
+            "queries": int(prob.shape[0]), "max_abs_prob_err": err, "labels_compared": int(safe.sum()),
+            "labels_identical": same, "parity": bool(err <= 1e-5 and same), "parity_tolerance": 1e-5}
 
 
 def secondary_shipped_model_e2e(device):
@@ -399,6 +450,10 @@ def secondary_shipped_model_e2e(device):
             "parity_tolerance": 1e-5, "parity_reads": ns}
         del dfull, res, sgq
         engm.close()
+        out["shipped_model_e2e"]["reference_model"] = reference_model_parity(device)
+        if out["shipped_model_e2e"]["reference_model"] is not None:
+            out["shipped_model_e2e"]["parity"] = bool(out["shipped_model_e2e"]["parity"] and
+                                                      out["shipped_model_e2e"]["reference_model"]["parity"])
     except ImportError:
         out["shipped_model_e2e"] = None
     return out["shipped_model_e2e"]
@@ -504,21 +559,21 @@ def secondary_regimes(device):
     # (jitter 2900: rows carry whole reads, adapter_start ~ U{100..3000} per read -- page-locked minibatches then take the
     # packed staging, only the windows cross the bus; feeder: ONE GPU-facing process, P producer processes fill a shared
     # page-locked ring -- always with the producers' own 40 MB fill per minibatch, like "pipe refill")
-    for mode, refill, Ps, jit in (("pipe", False, (1, 4), 0), ("pipe", False, (1, 2), 2900), ("sync", False, (1, 4, 16), 0),
-                                  ("sync", False, (1,), 2900), ("pipe", True, (4, 16), 2900), ("feeder", True, (4, 16), 2900)):
-        for P in Ps:
-            key = "%s%s%s_P%d" % (mode, "_refill" if (refill and mode != "feeder") else "", "_jitter" if jit else "", P)
-            cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
-                   "--seconds", "2", "--jitter", str(jit)] + (["--refill"] if (refill and mode != "feeder") else [])
-            if time.perf_counter() - t_hw > 90.0:   # a slow box must not stretch the default run: the rest is skipped, and says so
-                hw[key] = {"skipped": "leg budget of 90 s spent"}
-                continue
-            try:
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
-                rec = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
-            except Exception as e:  # noqa: BLE001
-                rec = {"error": f"{type(e).__name__}: {e}"}
-            hw[key] = rec
+    # (most telling first: the leg stops launching once 20 s are spent and says which configurations it skipped)
+    for mode, refill, P, jit in (("sync", False, 16, 0), ("sync", False, 4, 0), ("pipe", False, 1, 2900),
+                                 ("feeder", True, 16, 2900), ("pipe", True, 16, 2900), ("feeder", True, 4, 2900)):
+        key = "%s%s%s_P%d" % (mode, "_refill" if (refill and mode != "feeder") else "", "_jitter" if jit else "", P)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
+               "--seconds", "1.5", "--jitter", str(jit)] + (["--refill"] if (refill and mode != "feeder") else [])
+        if time.perf_counter() - t_hw > 20.0:   # the leg's budget: the rest is skipped, and says so
+            hw[key] = {"skipped": "leg budget of 20 s spent"}
+            continue
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
+            rec = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:  # noqa: BLE001
+            rec = {"error": f"{type(e).__name__}: {e}"}
+        hw[key] = rec
     good = [v for v in hw.values() if "reads_per_s" in v]
     out["host_workers"] = {
         "workload": "P forked worker processes on ONE GPU, each driving 1000 x 10 000 float32 minibatches (host buffers, PCIe "
@@ -692,17 +747,18 @@ def secondary_regimes(device):
         Xq = centers[yq] + 0.9 * rng.normal(size=(nq, L))
         model.predict(Xq, nproc=1)     # same size as the timed calls: the context's device buffers exist and are touched
         walls = []
-        for _ in range(3):
+        for _ in range(10):
             t0 = time.perf_counter()
             y_pred, y_prob = model.predict(Xq, nproc=1)
             walls.append(time.perf_counter() - t0)
-        dt = sum(walls) / len(walls)
+        dt = sorted(walls)[len(walls) // 2]      # the median of ten: a pageable 40 MB upload's wall time is noisy
         ns = 512
         Kq = np.exp(-orc.dtw_matrix(Xq[:ns], Xtr, WINDOW, PENALTY))  # float32 exp like the reference (dtw_svm.py:21-22)
         pref = svc.predict_proba(Kq)
         out["dtw_svm_predict"] = {
             "workload": "DTW_SVM.predict on 200 000 host fingerprints, WDX4-shaped model (851 x 25-pt rows, 5 classes), PCIe included",
-            "reads_per_s": nq / dt, "ms": dt * 1e3, "reps": len(walls), "ms_min": min(walls) * 1e3, "ms_max": max(walls) * 1e3,
+            "reads_per_s": nq / dt, "ms": dt * 1e3, "statistic": "median", "reps": len(walls), "ms_min": min(walls) * 1e3,
+            "ms_max": max(walls) * 1e3,
             "parity": bool(np.abs(y_prob[:ns] - pref).max() <= 1e-5), "max_abs_prob_err": float(np.abs(y_prob[:ns] - pref).max()),
             "parity_tolerance": 1e-5}
     except ImportError:
@@ -860,6 +916,17 @@ def run_rank(args):
         raise RuntimeError(f"rank {rank}: all-reduced call histogram does not add up: {counts.sum()} != {total}")
     if rank == 0 and n_fail > 0.01 * total:
         raise RuntimeError(f"{n_fail} of {total} reads failed: the synthetic workload should fingerprint cleanly")
+    # every read of the shard, on the device: the calls against the generator's true barcodes, per tenth of the shard
+    # (a launch slice that wrote nothing, or wrote another slice's reads, cannot pass this; the bitwise gate below
+    # samples the same range)
+    okd = res.status == 0
+    hit = ((res.call == bc) & okd).to(torch.float64)
+    edges = [n_reads * i // 10 for i in range(11)]
+    acc_tenths = [float(hit[a:b].sum().item() / max(int(okd[a:b].sum().item()), 1)) for a, b in zip(edges[:-1], edges[1:])]
+    accuracy = float(hit.sum().item() / max(int(okd.sum().item()), 1))
+    if min(acc_tenths) <= 0.75:
+        raise RuntimeError(f"rank {rank}: calls disagree with the generator's barcodes: accuracy per tenth of the shard {acc_tenths}")
+    del okd, hit
 
     # ---- roofline of the dominant kernel (algorithmic bytes, DESIGN.md "Measurement") ------------
     steps = max(args.steps, 1)
@@ -887,19 +954,26 @@ def run_rank(args):
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic of that kernel from the PMC passes (profiles/traffic.json, written by
     # tools/collect_traffic.py on the same workload); null when not collected for this size
-    traffic = None
+    # NOT measured by this run: PMC counters need rocprofv3 around the process, so these two figures are read from the
+    # committed passes of the same workload and carry their source (file, round) in the line
+    traffic = traffic_src = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("kernel") == dom and tj.get("reads_per_step") == n_reads:
             traffic = tj.get("hbm_bytes_per_step") / launches_per_step
+            traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "collected_by": "tools/collect_traffic.py "
+                           "(separate rocprofv3 --pmc passes of this command; not measured by this run)"}
     except (OSError, ValueError, TypeError):
         pass
-    valu_busy = None
+    valu_busy = valu_src = None
     try:
         with open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")) as fh:
-            pl = json.load(fh)["kernels"][dom.split("<")[0]]["per_launch"]
+            sj = json.load(fh)
+        pl = sj["kernels"][dom.split("<")[0]]["per_launch"]
         valu_busy = pl["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * pl["GRBM_GUI_ACTIVE"] / 8.0)
+        valu_src = {"file": "profiles/sq_counters_latest.json", "round": sj.get("round"),
+                    "collected_by": "tools/collect_sq.py (rocprofv3 --pmc pass of this command; not measured by this run)"}
     except (OSError, ValueError, KeyError):
         pass
 
@@ -928,6 +1002,8 @@ def run_rank(args):
                 "reads_per_gpu": per_gpu,
                 "reads_total": total,
                 "failed_reads": n_fail,
+                "call_accuracy_vs_true_barcode": {"whole_shard": accuracy, "min_over_tenths": min(acc_tenths),
+                                                  "asserted": "> 0.75 in every tenth of rank 0's shard (all reads, on the device)"},
                 **({"ctx_options": list(args.ctx_opt)} if args.ctx_opt else {}),
                 "sharding": "contiguous shards of one global read range (dist.shard_range), one process per GPU, "
                             "one int64[11] count all-reduce per step",
@@ -944,6 +1020,7 @@ def run_rank(args):
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": dom_n,
@@ -967,6 +1044,7 @@ def run_rank(args):
                    if dom == "fingerprint_fast_kernel" else {}),
                 # what actually bounds the kernel (float64 VALU issue), from the committed PMC pass
                 "valu_busy_frac": valu_busy,
+                "valu_busy_source": valu_src,
             },
             "kernels_ms_per_step": {   # HIP-event sums over all launches of a step (a step may be sliced)
                 "fingerprint": fp_ms / steps, "fingerprint_main_kernel": fpm_ms / steps,

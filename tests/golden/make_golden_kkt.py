@@ -1,15 +1,18 @@
-"""Fixture g9: the numeric parameters of the reference's five shipped DTW_SVM models, for the KKT pin
-of the DTW restatement (tests/helpers/kkt.py explains the conditions).
+"""Fixtures g9 / g9b: the numeric parameters of the reference's DTW_SVM models, for the KKT pin of the DTW
+restatement (tests/helpers/kkt.py explains the conditions).  g9 = the five shipped rna004 models
+(warpdemux/models/model_files, gamma 1, C 1); g9b = the six rna002 v0.4.4 models the reference keeps under
+DEPRECATED/model_files (gamma 1.2, C 10, up to 3 617 x 25 / 13 classes -- WDX12 is the model of the reference's
+live run, notebooks/Live_Run_8_FINAL_RUN_SARS2).
 
 Runs only in the build container (needs /root/reference).  It unpickles every
-warpdemux/models/model_files/*.joblib (reference DATA files, CC BY-NC: kept as a test fixture only),
+*.joblib of the two directories (reference DATA files, CC BY-NC: kept as a test fixture only),
 stores `_X`, the libsvm dual coefficients / intercepts / class bounds and the model's DTW parameters,
 and records the KKT residuals the oracle DTW and each negative control gave at generation time
 (`<model>__residuals`, rows in the order of `variant_names`; columns free_max_abs, bound_max,
 zero_min).  Nothing of dtaidistance is needed or stubbed with arithmetic here: the models themselves
 encode the genuine library's distances.
 
-    python tests/golden/make_golden_kkt.py        # writes tests/golden/g9_kkt_models.npz
+    python tests/golden/make_golden_kkt.py        # writes tests/golden/g9_kkt_models.npz and g9b_kkt_models_rna002.npz
 """
 import glob
 import os
@@ -47,10 +50,27 @@ def main():
     import joblib
 
     warnings.simplefilter("ignore")
+    only = sys.argv[1:]
+    for sub, dst_name in (("warpdemux/models/model_files", "g9_kkt_models.npz"),
+                          ("DEPRECATED/model_files", "g9b_kkt_models_rna002.npz")):
+        if only and dst_name.split("_")[0] not in only:
+            continue
+        make(joblib, sorted(glob.glob(os.path.join(REF, sub, "*.joblib"))), os.path.join(HERE, dst_name))
+
+
+def threaded(fn, X, w, p, rows=128):
+    """the oracle matrix in row blocks on all cores (ctypes drops the GIL): WDX12 is 13 M pairs"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as ex:
+        return np.concatenate(list(ex.map(lambda a: fn(X[a:a + rows], X, w, p), range(0, X.shape[0], rows))))
+
+
+def make(joblib, paths, dst):
     out = {}
     names = []
     vnames = None
-    for path in sorted(glob.glob(os.path.join(REF, "warpdemux/models/model_files/*.joblib"))):
+    for path in paths:
         name = os.path.basename(path).split("_")[0]
         m = joblib.load(path)
         svc = m.model
@@ -63,7 +83,7 @@ def main():
                "c_bound": np.asarray(svc.C * svc.class_weight_, dtype=np.float64),
                "gamma": np.float64(m.gamma), "pwr_dist": np.int32(m.pwr_dist),
                "window": np.int32(m.window), "penalty": np.float64(m.penalty)}
-        dtw = lambda X_, w, p: orc.dtw_matrix(X_, X_, w, p)  # noqa: E731
+        dtw = lambda X_, w, p: threaded(orc.dtw_matrix, X_, w, p)  # noqa: E731
         vs = kkt.variants(dtw, X, int(m.window), float(m.penalty))
         vnames = list(vs)
         rows = []
@@ -79,7 +99,6 @@ def main():
         names.append(name)
     out["models"] = np.array(names)
     out["variant_names"] = np.array(vnames)
-    dst = os.path.join(HERE, "g9_kkt_models.npz")
     np.savez_compressed(dst, **out)
     print(dst, os.path.getsize(dst), "bytes")
 

@@ -9,6 +9,9 @@ reference's outputs.  The un-vendored ``dtaidistance`` is absent from the image,
 oracle/wdx_oracle.c header); everything after the distance matrix is the reference + scikit-learn.
 
     python tests/golden/make_golden_svm.py        # writes tests/golden/g6_dtw_svm_wdx4.npz
+    python tests/golden/make_golden_svm.py more   # g6b (WDX10_rna004_v1_0: 2 601 x 25, 11 classes -- the headline's barcode
+                                                  # set) and g6c (DEPRECATED WDX12_rna002_v0_4_4: 3 617 x 25, 13 classes, gamma
+                                                  # 1.2 -- the model of the reference's live run); g6 itself is left alone
 """
 import os
 import sys
@@ -51,9 +54,18 @@ def main():
     import joblib
 
     warnings.simplefilter("ignore")
-    m = joblib.load(os.path.join(REF, "warpdemux/models/model_files/WDX4_rna004_v1_0.joblib"))
+    jobs = [("warpdemux/models/model_files/WDX4_rna004_v1_0.joblib", "g6_dtw_svm_wdx4.npz", 20261003)]
+    if sys.argv[1:] == ["more"]:
+        jobs = [("warpdemux/models/model_files/WDX10_rna004_v1_0.joblib", "g6b_dtw_svm_wdx10.npz", 20261004),
+                ("DEPRECATED/model_files/WDX12_rna002_v0_4_4.joblib", "g6c_dtw_svm_wdx12_rna002.npz", 20261005)]
+    for rel, dst, seed in jobs:
+        make(joblib, os.path.join(REF, rel), os.path.join(HERE, dst), seed)
+
+
+def make(joblib, path, out, seed):
+    m = joblib.load(path)
     svc = m.model
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(seed)
     # queries: training fingerprints with noise (confident calls), mixtures of two classes (low margins,
     # exercises the thresholds) and pure noise rows (the noise class)
     n_tr = m._X.shape[0]
@@ -64,7 +76,6 @@ def main():
     Xq = np.ascontiguousarray(np.vstack([a, b, c]))
     y_pred, y_prob = m.predict(Xq, nproc=1)
     df = m.predict(Xq, nproc=1, return_df=True)
-    out = os.path.join(HERE, "g6_dtw_svm_wdx4.npz")
     np.savez_compressed(
         out,
         X_train=m._X, window=m.window, penalty=m.penalty, block_size=m.block_size, gamma=m.gamma,

@@ -422,8 +422,9 @@ def test_fast_kernels_of_the_other_shipped_triples(triple):
     assert np.array_equal(sm.status, status[:700]) and _same(sm.fpt[good[:700]], fpt[:700][good[:700]])
 
 
+@pytest.mark.parametrize("max_slice", [0, 700])     # 700: every launch of the chain cut into slices (block_base != 0)
 @pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18)])
-def test_long_windows_in_large_batches_vs_oracle(triple):
+def test_long_windows_in_large_batches_vs_oracle(triple, max_slice):
     """3 000 reads whose windows straddle every capacity edge (5 120 / 6 144 / 8 192 / 11 200 / 16 384) through the
     launch chain: windows of 8 193 .. 16 384 samples take the streaming fast kernel, and what it declines beyond 11 200
     samples reaches fingerprint_big_kernel via the slow list."""
@@ -443,7 +444,8 @@ def test_long_windows_in_large_batches_vs_oracle(triple):
     a_s = np.zeros(n, dtype=np.int32)
     a_e = lens.astype(np.int32)
     kw = dict(padding=0, num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
-    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+    with _option(_lib.OPT_MAX_LAUNCH_SLICE, max_slice):
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
     fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
     big = lens > 16384
     assert (fb.status[big] == 5).all() and big.sum() == 1
@@ -916,12 +918,14 @@ def test_dtw_svm_predict_errors_and_single_row():
 
 
 @pytest.mark.gpu
-def test_dtw_svm_predict_reference_model_golden():
-    """g6: outputs of the reference's DTW_SVM.predict on its shipped WDX4_rna004_v1_0 model."""
+@pytest.mark.parametrize("which", ["WDX4_rna004", "WDX10_rna004", "WDX12_rna002"])
+def test_dtw_svm_predict_reference_model_golden(which):
+    """g6 / g6b / g6c: outputs of the reference's DTW_SVM.predict on its shipped WDX4 / WDX10 rna004 models and on
+    DEPRECATED WDX12_rna002 (3 617 x 25, 13 classes, gamma 1.2)."""
     from test_oracle_svm import load_g6
     from warpdemux_amd.models import DTW_SVM
 
-    g, label_mapper = load_g6()
+    g, label_mapper = load_g6(which)
     m = DTW_SVM(g["X_train"], g["n_support"], g["support"], g["dual_coef"], -g["intercept"], g["probA"], g["probB"],
                 label_mapper, g["thresholds"], window=int(g["window"]), penalty=float(g["penalty"]),
                 gamma=float(g["gamma"]), pwr_dist=int(g["pwr_dist"]), block_size=int(g["block_size"]))
@@ -998,6 +1002,56 @@ def test_full_size_properties_one_million_reads(n_bc):
         assert np.array_equal(r1.call[lo:hi].cpu().numpy()[okb], orc.argmin_rows(D))
         checked += int(okb.sum())
     assert checked > 19_900
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [False, True])
+def test_sliced_launches_of_a_30k_read_batch_vs_oracle(exact):
+    """A pass over more reads than one grid admits is cut into equal launch slices with block_base != 0
+    (wdx_fingerprint.hip `launch_sliced`, `launch_fp_chunks`, the clip launches): C3 runs 2 x 5 M.  Here the slice is
+    forced down (WDX_OPT_MAX_LAUNCH_SLICE) so that 30 000 reads run as five slices of the main kernel, eight of the
+    clip kernel, and the list kernels' entries straddle slices -- every read of every slice against the oracle, bitwise,
+    through the fused call (fingerprint -> DTW -> call -> histogram) and through the fingerprint entry point."""
+    import torch
+
+    from bench import make_refs
+    from warpdemux_amd.engine import DemuxEngine
+
+    spec = synth.SynthSpec(n_barcodes=10)
+    K, n = 110, 30_000
+    refs = make_refs(synth.SynthSpec(n_barcodes=10, noise_sigma=0.25, spikes=False), synth, sig_proc, n_barcodes=10)
+    eng = DemuxEngine(refs, 15, 0.1, sig_proc.SegParams(barcode_num_events=K))
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 7_000_000, n)
+    whole = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, want_fpt=True)
+    eng.ctx.set_option(_lib.OPT_MAX_LAUNCH_SLICE, 6_000 if not exact else 7_001)   # (7 001: a short last slice)
+    eng.ctx.set_option(_lib.OPT_EXACT_PATH, int(exact))
+    try:
+        sl = eng.demux(sig, a_s, a_e, offsets=off, max_len=max_len, want_fpt=True)
+        f_fpt, f_dwell, f_stats, f_status = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len)
+    finally:
+        eng.ctx.set_option(_lib.OPT_MAX_LAUNCH_SLICE, 0)
+        eng.ctx.set_option(_lib.OPT_EXACT_PATH, 0)
+    torch.cuda.synchronize()
+    # sliced == unsliced, everything
+    assert torch.equal(sl.call, whole.call) and torch.equal(sl.status, whole.status) and torch.equal(sl.counts, whole.counts)
+    assert torch.equal(sl.dist.view(torch.int32), whole.dist.view(torch.int32))
+    assert torch.equal(sl.fpt.view(torch.int64), whole.fpt.view(torch.int64))
+    assert torch.equal(f_fpt.view(torch.int64), whole.fpt.view(torch.int64)) and torch.equal(f_status, whole.status)
+    # ... == the oracle, every read
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig.cpu().numpy(), off.cpu().numpy().astype(np.int64),
+                                                       a_s.cpu().numpy(), a_e.cpu().numpy(), orc.SegParams(barcode_num_events=K))
+    assert np.array_equal(status, sl.status.cpu().numpy())
+    ok = status == 0
+    assert ok.mean() > 0.999
+    assert np.array_equal(sl.fpt.cpu().numpy()[ok].view(np.uint64), fpt[ok].view(np.uint64))
+    assert np.array_equal(f_dwell.cpu().numpy()[ok], dwell[ok]) and _same(f_stats.cpu().numpy()[ok], stats[ok])
+    D = orc.dtw_matrix(fpt[ok], refs, 15, 0.1)
+    assert np.array_equal(sl.dist.cpu().numpy()[ok].view(np.uint32), D.view(np.uint32))
+    assert np.array_equal(sl.call.cpu().numpy()[ok], orc.argmin_rows(D))
+    counts = sl.counts.cpu().numpy()
+    assert counts.sum() == n and counts[-1] == int((~ok).sum())
+    assert np.array_equal(counts[:-1], np.bincount(orc.argmin_rows(D), minlength=10))
     eng.close()
 
 

@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r04b}
+TAG=${1:-r05a}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -12,14 +12,14 @@ python3 bench.py > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err
 D=gpurun_out/${TAG}_stats; rm -rf $D
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$D -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu --no-secondary) > gpurun_out/${TAG}_bench_under_rocprof.log 2>&1
 cp $(find $D -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_kernel_stats.csv 2>/dev/null
-python3 tools/collect_traffic.py --out gpurun_out/${TAG}_traffic > gpurun_out/${TAG}_traffic.log 2>&1
+python3 tools/collect_traffic.py --tag ${TAG} --out gpurun_out/${TAG}_traffic > gpurun_out/${TAG}_traffic.log 2>&1
 cp profiles/traffic.json gpurun_out/${TAG}_traffic.json 2>/dev/null
 python3 tools/collect_sq.py --tag ${TAG} --out gpurun_out/${TAG}_sq > gpurun_out/${TAG}_sq.log 2>&1
 python3 tools/phase_counters.py 262144 > gpurun_out/${TAG}_phase_counters.txt 2> gpurun_out/${TAG}_phase_counters.err
 python3 tools/profile_fingerprint.py 16384 1 1000000 > gpurun_out/${TAG}_fast_kernel_phase_shares.txt 2>&1
 python3 tools/long_window_bench.py 110 15 30 8192 > gpurun_out/${TAG}_window_lengths.txt 2>&1
 python3 tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine.txt 2>&1
-GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} bash tools/dev/rfstats.sh > gpurun_out/${TAG}_refine_kernel_trace.txt 2>&1
+bash tools/dev/rfstats.sh > gpurun_out/${TAG}_refine_kernel_trace.txt 2>&1
 python3 tools/pmc_kernel.py refine_tail_kernel,refine_match_wave,fingerprint_list_kernel -- python3 $PWD/tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine_sq_counters.txt 2>&1
 python3 bench.py --leg shipped_model_e2e > gpurun_out/${TAG}_shipped_model_e2e.json 2> /dev/null
 for t in "110 6 12" "110 15 30" "120 9 18"; do python3 tools/profile_exact.py $t 65536 >> gpurun_out/${TAG}_exact_kernel_triples.txt 2>&1; done

@@ -58,7 +58,7 @@ def main():
             c = d.setdefault(r["Counter_Name"], [0.0, 0])
             c[0] += float(r["Counter_Value"])
             c[1] += 1
-    out = {"reads_per_launch": args.reads, "kernels": {}, "source": "rocprofv3 --kernel-trace --pmc (two passes), "
+    out = {"round": args.tag, "reads_per_launch": args.reads, "kernels": {}, "source": "rocprofv3 --kernel-trace --pmc (two passes), "
            "tools/collect_sq.py; per-launch averages, SQ cycle counters in quad-cycles summed over waves"}
     for k, d in res.items():
         avg = {c: v[0] / v[1] for c, v in d.items()}

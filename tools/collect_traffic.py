@@ -54,6 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "traffic"))
+    ap.add_argument("--tag", default="r05", help="round tag recorded in the JSON (bench.py prints it as the figure's source)")
     ap.add_argument("--parse-only", action="store_true", help="re-read existing CSVs under --out")
     args = ap.parse_args()
     args.out = os.path.abspath(args.out)
@@ -75,6 +76,7 @@ def main():
     write_b = wk * 1024.0 / wn
     res = {
         "kernel": "fingerprint_fast_kernel",
+        "round": args.tag,
         "reads_per_launch": n_reads // max(fn // 2, 1),
         # what bench.py looks up: the whole step (all launch slices of one pass over the batch)
         "reads_per_step": n_reads,

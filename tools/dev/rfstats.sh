@@ -1,9 +1,13 @@
+#!/bin/bash
 # per-kernel durations of the tRNA refinement flow (rocprofv3 --kernel-trace --stats over tools/bench_refine.py 32768)
+set -u
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+mkdir -p "$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/rf
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/rf -- python3 $GRAFT_REPO_ROOT/tools/bench_refine.py 32768 > $GRAFT_REPO_ROOT/gpurun_out/rf.log 2>&1
-tail -2 $GRAFT_REPO_ROOT/gpurun_out/rf.log
-python3 - $(find $GRAFT_REPO_ROOT/gpurun_out/rf -name "*kernel_trace.csv" | head -1) <<'PY'
+rm -rf $ROOT/gpurun_out/rf
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/rf -- python3 $ROOT/tools/bench_refine.py 32768 > $ROOT/gpurun_out/rf.log 2>&1
+tail -2 $ROOT/gpurun_out/rf.log
+python3 - $(find $ROOT/gpurun_out/rf -name "*kernel_trace.csv" | head -1) <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))

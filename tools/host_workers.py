@@ -155,7 +155,13 @@ def feeder_mode(args):
                             done_q[pid].put(sl)
                             counts[0] += 1
                     except Exception as e:  # noqa: BLE001
+                        # abort: the submit loop stops (ready_q "stop"), every producer is told (done_q sentinel -1) so none
+                        # of them spins on a minibatch that will never come back, the parent gets the error at once
                         errors.append(f"{type(e).__name__}: {e}")
+                        res_q.put({"error": f"feeder waiter {errors[0]}"})
+                        for dq in done_q:
+                            dq.put(-1)
+                        ready_q.put("stop")
 
                 wt = threading.Thread(target=waiter)
                 wt.start()
@@ -163,6 +169,8 @@ def feeder_mode(args):
                     item = ready_q.get()
                     if item == "stop":
                         break
+                    if errors:
+                        continue
                     sl, pid = item
                     pipe.submit(sl, ring[sl], mv[sl, :N_READS], mv[sl, N_READS:2 * N_READS])
                     inflight.put((sl, pid))
@@ -194,8 +202,12 @@ def feeder_mode(args):
 
                 n, pending, last = 0, [], None
 
+                deadline = t0 + args.seconds + 120.0      # hard stop: a producer never outlives a dead feeder
+
                 def finish(sl):
                     nonlocal n, last
+                    if sl < 0:
+                        raise RuntimeError("the feeder aborted")
                     pending.remove(sl)
                     last = (mv[sl, 2 * N_READS:3 * N_READS].copy(), mv[sl, 3 * N_READS:4 * N_READS].copy(),
                             mv[sl, 4 * N_READS:].copy().view(np.float32).reshape(N_READS, N_REFS))
@@ -208,6 +220,8 @@ def feeder_mode(args):
                     active = time.perf_counter() - t0 < args.seconds
                     if not active and not pending:
                         break
+                    if time.perf_counter() > deadline:
+                        raise RuntimeError("no result from the feeder for 120 s")
                     progressed = False
                     if pending:
                         try:
@@ -250,11 +264,19 @@ def feeder_mode(args):
         procs = [ctx.Process(target=producer, args=(i,)) for i in range(P)]
         for p_ in procs:
             p_.start()
-        res = [res_q.get(timeout=600) for _ in procs]
-        ready_q.put("stop")
-        res.append(res_q.get(timeout=120))
+        res = []
+        try:
+            for _ in procs:
+                res.append(res_q.get(timeout=600))
+                if "error" in res[-1]:
+                    break
+            ready_q.put("stop")
+            if not any("error" in r for r in res):
+                res.append(res_q.get(timeout=120))
+        except Exception as e:  # noqa: BLE001  (queue.Empty: a child hangs)
+            res.append({"error": f"parent {type(e).__name__}: {e}"})
         for p_ in procs + [fp]:
-            p_.join(60)
+            p_.join(0.0 if any("error" in r for r in res) else 60)
         errs = [r for r in res if "error" in r]
         if errs:
             print(json.dumps({"error": errs}))
@@ -268,6 +290,11 @@ def feeder_mode(args):
         print(json.dumps(out))
         return 0 if out["parity"] else 2
     finally:
+        # no child outlives the shared memory: whatever still runs (a hung feeder holds the GPU) is ended first
+        for p_ in list(locals().get("procs", [])) + [locals().get("fp")]:
+            if p_ is not None and p_.is_alive():
+                p_.terminate()
+                p_.join(10)
         del ring, mv
         shm.close()
         shm.unlink()

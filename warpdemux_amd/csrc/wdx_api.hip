@@ -19,6 +19,12 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+static thread_local int64_t g_slice_cap = 0;   // WDX_OPT_MAX_LAUNCH_SLICE of the call running on this thread (0 = none)
+
+int64_t launch_slice_limit(int64_t builtin) { return g_slice_cap > 0 && g_slice_cap < builtin ? g_slice_cap : builtin; }
+LaunchSliceScope::LaunchSliceScope(int64_t cap) : saved(g_slice_cap) { g_slice_cap = cap; }
+LaunchSliceScope::~LaunchSliceScope() { g_slice_cap = saved; }
+
 // content hash of the reference set (cache key): 64-bit words, multiply-xorshift mixing
 static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
     const unsigned char *p = (const unsigned char *)data;
@@ -102,35 +108,33 @@ DeviceGuard::~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
+// one event pair from the context's pool, or two fresh events -- both or neither (a failed second create must not leak
+// the first)
+static std::pair<hipEvent_t, hipEvent_t> take_event_pair(wdx_ctx *c) {
+    std::pair<hipEvent_t, hipEvent_t> q{nullptr, nullptr};
+    if (!c->pool.empty()) {
+        q = c->pool.back();
+        c->pool.pop_back();
+        return q;
+    }
+    if (hipEventCreate(&q.first) != hipSuccess) return {nullptr, nullptr};
+    if (hipEventCreate(&q.second) != hipSuccess) {
+        (void)hipEventDestroy(q.first);
+        return {nullptr, nullptr};
+    }
+    return q;
+}
+
 Timed::Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
     if (!c->timing) return;
-    if (!c->pool.empty()) {
-        ev = c->pool.back();
-        c->pool.pop_back();
-    } else {
-        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
-            ev = {nullptr, nullptr};
-            return;
-        }
-    }
+    ev = take_event_pair(c);
+    if (!ev.first) return;
     (void)hipEventRecord(ev.first, s);
     if (id == WDX_K_FINGERPRINT) {  // a second pair for the main fast-kernel launches (recorded by launch_fingerprint)
-        std::pair<hipEvent_t, hipEvent_t> m{nullptr, nullptr};
-        if (!c->pool.empty()) {
-            m = c->pool.back();
-            c->pool.pop_back();
-        } else if (hipEventCreate(&m.first) != hipSuccess || hipEventCreate(&m.second) != hipSuccess) {
-            m = {nullptr, nullptr};
-        }
+        const auto m = take_event_pair(c);
         main.first = m.first;
         main.second = m.second;
-        std::pair<hipEvent_t, hipEvent_t> q{nullptr, nullptr};
-        if (!c->pool.empty()) {
-            q = c->pool.back();
-            c->pool.pop_back();
-        } else if (hipEventCreate(&q.first) != hipSuccess || hipEventCreate(&q.second) != hipSuccess) {
-            q = {nullptr, nullptr};
-        }
+        const auto q = take_event_pair(c);   // ... and a third around clip_bounds_kernel
         main.c_first = q.first;
         main.c_second = q.second;
     }
@@ -431,6 +435,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_FAST_MAIN_CAP: ctx->knobs.fast_main_cap = (int)value; break;
         case WDX_OPT_FAST_CHAIN_MIN_READS: ctx->knobs.fast_chain_min = (int)value; break;
         case WDX_OPT_EXACT_NO_PEAK_LIST: ctx->knobs.exact_no_list = value != 0; break;
+        case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);
             return WDX_ERR_INVALID;
@@ -935,7 +940,7 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
         if ((rc = launch_fingerprint((const float *)B->in0.p, d_off, d_len, 0, max_len, n_reads, d_as, d_ae,
                                      ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p, nullptr, nullptr,
                                      (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
-                                     nullptr, (double *)B->fp_big.p)))
+                                     &t.main, (double *)B->fp_big.p)))
             return rc;
     } else {
         const float *d_sig = (const float *)B->in0.p;
@@ -951,7 +956,7 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
                                      (const int32_t *)B->in1.p, (const int32_t *)B->in2.p,
                                      ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p,
                                      nullptr, nullptr, (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches,
-                                     nullptr, 0, 0, nullptr, nullptr, (double *)B->fp_big.p)))
+                                     nullptr, 0, 0, nullptr, &t.main, (double *)B->fp_big.p)))
             return rc;
     }
     if (R.nY > 0) {

@@ -523,7 +523,7 @@ int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_c
                             hipStream_t stream) {
     if (n_entries <= 0) return WDX_SUCCESS;
     ClipArgs CA{A, d_rec, 6144, d_count, d_list};
-    const int64_t n_wg = (n_entries + kClipWaves - 1) / kClipWaves, max_slice = 1ll << 22;
+    const int64_t n_wg = (n_entries + kClipWaves - 1) / kClipWaves, max_slice = launch_slice_limit(1ll << 22);
     for (int64_t base = 0; base < n_wg; base += max_slice) {
         CA.a.block_base = base * kClipWaves;
         hipLaunchKernelGGL(clip_bounds_list_kernel<96>, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)),
@@ -540,7 +540,7 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
     }
     void (*kclip)(ClipArgs) = cap <= 4096 ? clip_bounds_kernel<64> : (cap <= 5120 ? clip_bounds_kernel<80> : clip_bounds_kernel<96>);
     ClipArgs CA{A, d_rec, cap, nullptr, nullptr};
-    const int64_t n_wg = (A.n_reads + kClipWaves - 1) / kClipWaves, max_slice = 1ll << 22;
+    const int64_t n_wg = (A.n_reads + kClipWaves - 1) / kClipWaves, max_slice = launch_slice_limit(1ll << 22);
     for (int64_t base = 0; base < n_wg; base += max_slice) {
         CA.a.block_base = base * kClipWaves;
         hipLaunchKernelGGL(kclip, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)), dim3(kClipWaves * 64), 0, stream, CA);

@@ -33,6 +33,17 @@ struct Knobs {
     int fast_main_cap = 0;      // WDX_OPT_FAST_MAIN_CAP: 5120 / 6144 forces the main fast instantiation (0 = by batch)
     bool fast_exact_scores = false;  // WDX_OPT_FAST_EXACT_SCORES: fast fingerprint kernel without the approximate first attempt
     bool exact_no_list = false;      // WDX_OPT_EXACT_NO_PEAK_LIST: exact kernel's suppression / top-E in position space only
+    int64_t max_launch_slice = 0;    // WDX_OPT_MAX_LAUNCH_SLICE: upper bound of one launch slice of the fingerprint chain (0 = built-in)
+};
+
+// A launch over more workgroups than grid.x admits is cut into slices (block_base != 0 from the second on).  The built-in
+// slice sizes are millions of workgroups; WDX_OPT_MAX_LAUNCH_SLICE lowers them for the calling thread while one
+// launch_fingerprint runs, so that the tests walk the multi-slice paths on batches the oracle finishes in seconds.
+int64_t launch_slice_limit(int64_t builtin);
+struct LaunchSliceScope {
+    explicit LaunchSliceScope(int64_t cap);
+    ~LaunchSliceScope();
+    int64_t saved;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): a launch on the live

@@ -1553,7 +1553,7 @@ static int launch_refine_tail(FpArgs A, unsigned *slow_count, int32_t *slow_list
     static LdsAttr attr_t;
     const size_t lds_t = refine_tail_lds_bytes();
     if (int rc = attr_t.ensure(fingerprint_refine_tail_kernel<256>, lds_t)) return rc;
-    const int64_t slice = 1 << 22;
+    const int64_t slice = launch_slice_limit(1 << 22);
     for (int64_t base = 0; base < A.n_reads; base += slice) {
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
@@ -1611,7 +1611,7 @@ static int launch_fp_chunks(FpArgs A, size_t lds, hipStream_t stream, int64_t *n
     static LdsAttr attr;
     if (int rc = attr.ensure(fingerprint_kernel<BLOCK, PROF>, lds)) return rc;
     // HIP drops work when grid.x * block.x reaches 2^32: launch in slices of 2^21 reads
-    const int64_t slice = 1 << 21;
+    const int64_t slice = launch_slice_limit(1 << 21);
     for (int64_t base = 0; base < A.n_reads; base += slice) {
         const int64_t n = A.n_reads - base < slice ? A.n_reads - base : slice;
         A.block_base = base;
@@ -1698,6 +1698,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         set_error("at most 2^31-1 reads per call");
         return WDX_ERR_INVALID;
     }
+    LaunchSliceScope slice_scope(knobs.max_launch_slice);
     if (p.num_events < 1 || p.num_events > kMaxEvents) {
         set_error("num_events must be in [1, %d]", kMaxEvents);
         return p.num_events < 1 ? WDX_ERR_INVALID : WDX_ERR_UNSUPPORTED;
@@ -1858,7 +1859,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // one workgroup per read (or list entry); grid.x * block.x must stay below 2^32: equal launch slices of at
         // most 2^31 / FB workgroups
         auto launch_sliced = [&](void (*k)(FastArgs), FastArgs &fa, int64_t n_wg, size_t lds_bytes, bool counted) {
-            const int64_t max_slice = (1ll << 31) / FB, n_slices = (n_wg + max_slice - 1) / max_slice;
+            const int64_t max_slice = launch_slice_limit((1ll << 31) / FB), n_slices = (n_wg + max_slice - 1) / max_slice;
             const int64_t slice = (n_wg + n_slices - 1) / n_slices;
             for (int64_t base = 0; base < n_wg; base += slice) {
                 const int64_t n = n_wg - base < slice ? n_wg - base : slice;
@@ -1924,7 +1925,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             static LdsAttr attr_cb, attr_st[3];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
-            const int64_t max_slice = 1ll << 22;
+            const int64_t max_slice = launch_slice_limit(1ll << 22);
             for (int64_t base = 0; base < n_reads; base += max_slice) {
                 ClipBlockArgs CB{A, clip, count + 4, big2, scap};
                 CB.a.block_base = base;

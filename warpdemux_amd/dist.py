@@ -146,7 +146,7 @@ class CountReducer:
         _lib.check(self._L.wdx_comm_init(self.ctx.handle, payload, rank, world))
         r, w, cnt = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
         _lib.check(self._L.wdx_comm_info(self.ctx.handle, C.byref(r), C.byref(w), C.byref(cnt)))
-        if (r.value, w.value) != (rank, world) or cnt.value not in (world, -1):
+        if (r.value, w.value) != (rank, world) or cnt.value != world:
             raise _lib.WdxError(f"RCCL communicator reports {cnt.value} ranks (bound as rank {r.value} of {w.value}); "
                                 f"the process group has {world}")
         self.rccl_ranks = cnt.value

@@ -115,11 +115,14 @@ class MinibatchPipeline:
         fpt = np.empty((n, self.K), dtype=np.float64) if want_fpt else None
         call = np.empty(n, dtype=np.int32)
         status = np.empty(n, dtype=np.int32)
-        try:
-            _lib.check(self.L.wdx_demux_wait(self.ctx.handle, int(slot), _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call),
-                                             _lib.ptr(status)))
-        finally:
+        rc = self.L.wdx_demux_wait(self.ctx.handle, int(slot), _lib.ptr(fpt), _lib.ptr(dist), _lib.ptr(call),
+                                   _lib.ptr(status))
+        # WDX_ERR_INVALID (an argument error, or another thread already waiting on this slot) leaves the minibatch IN
+        # FLIGHT in the slot (wdx.h): the copy-in may still be reading the arrays, so they stay referenced and the
+        # caller can wait again.  Success and a HIP error both free the slot on the C side.
+        if rc != _lib.WDX_ERR_INVALID:
             self._held[slot] = None
+        _lib.check(rc)
         return DemuxBatch(status, call, dist, fpt)
 
     def run(self, minibatches):
