@@ -114,6 +114,7 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_FAST_CHAIN_MIN_READS 9 /* smallest batch that takes the approximate-keys launch chain (0 = 2048) */
 #define WDX_OPT_EXACT_NO_PEAK_LIST 10  /* exact kernel: suppression / top-E over positions, never over the peak list */
 #define WDX_OPT_MAX_LAUNCH_SLICE 11    /* fingerprint chain: at most this many workgroups per launch slice (0 = built-in) */
+#define WDX_OPT_NO_PEAK_FILTER 12      /* fast fingerprint kernels: no threshold filter of the peak list (every local maximum) */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

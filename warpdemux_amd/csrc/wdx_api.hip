@@ -435,6 +435,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_FAST_MAIN_CAP: ctx->knobs.fast_main_cap = (int)value; break;
         case WDX_OPT_FAST_CHAIN_MIN_READS: ctx->knobs.fast_chain_min = (int)value; break;
         case WDX_OPT_EXACT_NO_PEAK_LIST: ctx->knobs.exact_no_list = value != 0; break;
+        case WDX_OPT_NO_PEAK_FILTER: ctx->knobs.no_peak_filter = value != 0; break;
         case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);

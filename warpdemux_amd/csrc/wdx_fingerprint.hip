@@ -1784,16 +1784,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
         // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
         // Large batches: the clip bounds of the MAIN kernel's reads are computed ahead of it by clip_bounds_kernel (one wave
-        // per read, wdx_clip.hip) and the main kernel starts at the clip (EXT instantiation) with its peak list overlaying
-        // the consumed samples (fast_sh_offset): six workgroups per CU at 5120 samples, five at 6144.  The list kernels
-        // behind it (a tenth of the reads, longer windows) and small batches (live ticks: every launch counts) keep the
-        // in-kernel radix selects and the layout with the peak list behind the samples.
+        // per read, wdx_clip.hip) and the main kernel starts at the clip (EXT instantiation).  Small batches (live ticks:
+        // every launch counts) keep the in-kernel radix selects.
         const bool ext = large_batch || capF == 5120;
-        const bool ovl = ext && (WDX_EXT_OVERLAY != 0);
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
-        if (ovl) capP = capF == 4096 ? 1400 : (capF == 5120 ? 1800 : 2040);  // (3 bytes per peak beside the samples)
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
-        const size_t flds = fast_lds_bytes(capF, capP, nbt, ovl);
+        const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
         ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 32);
         int32_t *list = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_ws) + 32 + 16 * n_reads);
@@ -1806,6 +1802,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool with_stream = chain && ext && capF >= 5120 && max_len > 6144;
         const bool with_big1 = chain && capF >= 5120 && cap > 6144 && !with_stream;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
+        A.peak_filter = knobs.no_peak_filter ? 0 : 1;   // (only the approximate-keys launches look at it)
         FastArgs F{A, capF, capP, count, list, nullptr, nullptr, nullptr, nullptr, 0u, approx ? count + 3 : nullptr,
                    approx ? retry : nullptr, nullptr};
         if (with_big0) {

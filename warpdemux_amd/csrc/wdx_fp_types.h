@@ -68,6 +68,7 @@ struct FpArgs {
     int no_list;         // WDX_OPT_EXACT_NO_PEAK_LIST: fp_segment in position space only (diagnostic)
     int refine_record;   // exact kernel, refinement branch: 1 = leave a RefineRec for the refinement kernels where the read
                          // allows it (no NaN in the window, configured window width) instead of refining in place
+    int peak_filter;     // fast kernels on approximate keys: 1 = drop peaks below kPeakTau at the append (WDX_OPT_NO_PEAK_FILTER)
 };
 
 // Clip bounds of one read, computed ahead of the fast kernels' launch chain by clip_bounds_kernel (one wave per read,
