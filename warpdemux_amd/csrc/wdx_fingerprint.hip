@@ -1788,6 +1788,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // every launch counts) keep the in-kernel radix selects.
         const bool ext = large_batch || capF == 5120;
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
+        // with the threshold filter of the appends (kPeakTau) a read lists ~200 peaks instead of ~830: 512 entries leave the
+        // 5120-sample main kernel at 26.8 KB of LDS -- six workgroups per CU (a longer list moves on to the list kernels)
+        if (ext && approx && !knobs.no_peak_filter && combo == 1 && capF <= 5120) capP = 512;
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
