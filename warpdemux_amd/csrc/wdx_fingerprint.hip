@@ -1790,7 +1790,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
         // with the threshold filter of the appends (kPeakTau) a read lists ~200 peaks instead of ~830: 512 entries leave the
         // 5120-sample main kernel at 26.8 KB of LDS -- six workgroups per CU (a longer list moves on to the list kernels)
-        if (ext && approx && !knobs.no_peak_filter && combo == 1 && capF <= 5120) capP = 512;
+        const bool filt = approx && !knobs.no_peak_filter && nbt == 1;   // (the launches on approximate keys below)
+        if (ext && filt && capF <= 5120) capP = 512;
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
@@ -1888,6 +1889,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const int64_t grid = n_reads < 1024 ? n_reads : 1024;  // striding kernels: every CU busy, nothing more
         const int capF1 = 6144, capP1 = 1376, capF2 = 8192, capP2 = 1856;
         const size_t flds1 = fast_lds_bytes(capF1, capP1, nbt), flds2 = fast_lds_bytes(capF2, capP2, nbt);
+        // the same kernels behind filtered appends (the approximate-keys launches; the exact-scores retry keeps the long
+        // lists): 512 entries -> five workgroups per CU at 6144 samples, four at 8192
+        const int capP1f = filt ? 512 : capP1, capP2f = filt ? 512 : capP2;
+        const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
         static LdsAttr attr_l1[3], attr_huge[3];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
@@ -1897,20 +1902,20 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // 11 % of RNA004 adapter windows are longer than 5120 samples: a grid for a quarter of the batch, one
             // workgroup per list entry, and the striding 8192-sample kernel for whatever lies beyond it
             const int64_t g1 = std::min<int64_t>(n_reads, std::max<int64_t>(1024, n_reads / 4));
-            FastArgs F1{A, capF1, capP1, count, list, with_stream ? count + 4 : (with_big1 ? count + 2 : nullptr),
+            FastArgs F1{A, capF1, capP1f, count, list, with_stream ? count + 4 : (with_big1 ? count + 2 : nullptr),
                         with_stream ? big2 : (with_big1 ? big1 : nullptr), count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
             if (int rc = launch_clip_bounds_list(A, clip, count + 1, big0, g1, stream)) return rc;
-            launch_sliced(kern_l1, F1, g1, flds1, false);
+            launch_sliced(kern_l1, F1, g1, flds1f, false);
             if (g1 < n_reads) {
-                FastArgs F1b{A, capF2, capP2, count, list, with_stream ? count + 4 : nullptr, with_stream ? big2 : nullptr,
+                FastArgs F1b{A, capF2, capP2f, count, list, with_stream ? count + 4 : nullptr, with_stream ? big2 : nullptr,
                              count + 1, big0, (unsigned)g1, F.retry_count, F.retry_list, nullptr};
-                hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2,
+                hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2f,
                                    stream, F1b);
             }
         }
         if (with_big1) {
-            FastArgs F2{A, capF2, capP2, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list, nullptr};
-            hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2, stream,
+            FastArgs F2{A, capF2, capP2f, count, list, nullptr, nullptr, count + 2, big1, 0u, F.retry_count, F.retry_list, nullptr};
+            hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2f, stream,
                                F2);
         }
         if (with_stream) {
@@ -1920,7 +1925,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // up to 16 384.  One workgroup per entry; the list's length is only known on the device, so the grid covers
             // the batch (a workgroup past the list's end leaves at once).  Doubts and refusals go to the exact kernel.
             const int scap = max_len <= 8192 ? 8192 : (max_len <= 12288 ? 12288 : 16384);
-            const int capPs = scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400);
+            const int capPs = filt ? 1024 : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
             static LdsAttr attr_cb, attr_st[3];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
