@@ -1788,10 +1788,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // every launch counts) keep the in-kernel radix selects.
         const bool ext = large_batch || capF == 5120;
         int capP = capF == 4096 ? 1152 : (capF == 5120 ? 980 : 1376);
-        // with the threshold filter of the appends (kPeakTau) a read lists ~200 peaks instead of ~830: 512 entries leave the
-        // 5120-sample main kernel at 26.8 KB of LDS -- six workgroups per CU (a longer list moves on to the list kernels)
-        const bool filt = approx && !knobs.no_peak_filter && nbt == 1;   // (the launches on approximate keys below)
-        if (ext && filt && capF <= 5120) capP = 512;
+        // with the threshold filter of the appends (kPeakTauLo) a read lists ~340 peaks instead of ~830: 512 entries leave the
+        // 5120-sample main kernel at 26.8 KB of LDS -- six workgroups per CU (a longer list moves on to the list kernels).
+        // (the width-30 instantiations, NBT = 2, are bound by their registers at four: they keep the long lists, except
+        // the streaming form)
+        const bool filt = approx && !knobs.no_peak_filter;   // (the launches on approximate keys below)
+        if (ext && filt && nbt == 1 && capF <= 5120) capP = 512;
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
@@ -1891,7 +1893,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const size_t flds1 = fast_lds_bytes(capF1, capP1, nbt), flds2 = fast_lds_bytes(capF2, capP2, nbt);
         // the same kernels behind filtered appends (the approximate-keys launches; the exact-scores retry keeps the long
         // lists): 512 entries -> five workgroups per CU at 6144 samples, four at 8192
-        const int capP1f = filt ? 512 : capP1, capP2f = filt ? 512 : capP2;
+        const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 512 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
         static LdsAttr attr_l1[3], attr_huge[3];
         if (with_big0 || (approx && chain))
