@@ -1131,6 +1131,31 @@ def test_launch_chain_lists_longer_than_their_grids():
     assert _same(fc.fpt[sub][good], fpt[good]) and _same(fc.dwell[sub][good], dwell[good])
 
 
+def test_streaming_list_longer_than_its_grid():
+    """Up to 8192 samples the streaming kernels' grids cover a sixteenth of the batch (at least 4096 entries) and the
+    striding 8192-sample kernel takes the list entries beyond: a batch in which EVERY window has 6200 .. 8000 samples
+    (4 608 list entries) still matches the oracle, on either side of the grid's end."""
+    rng = np.random.default_rng(78)
+    n, stride = 4608, 8064
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    lens = rng.integers(6200, 8001, n)
+    for i, ln in enumerate(lens):
+        ev = int(rng.integers(25, 55))
+        lvl = np.repeat(rng.normal(85, 14, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = (lvl + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = lens.astype(np.int32)
+    ph, po = sig_proc.SegParams(padding=0, barcode_num_events=25), orc.SegParams(padding=0, barcode_num_events=25)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    sub = np.concatenate([np.arange(0, 4000, 16), np.arange(4000, n, 3)])   # (list order is arbitrary: sample everywhere)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb[sub], a_s[sub], a_e[sub], po)
+    assert np.array_equal(fb.status[sub], status) and (status == 0).mean() > 0.98
+    assert _same(fb.fpt[sub], fpt) and _same(fb.dwell[sub], dwell) and _same(fb.stats[sub], stats)
+    with _exact_path():
+        sl = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    assert np.array_equal(fb.status, sl.status) and _same(fb.fpt, sl.fpt) and _same(fb.dwell, sl.dwell)
+
+
 def test_window_lengths_at_every_capacity_and_chunk_edge():
     """Windows exactly at, one below and one above every instantiation's capacity, at multiples of the 1024-sample
     step that sets a thread's chunk of the event-mean prefix sums (where the last thread owns a full chunk or the

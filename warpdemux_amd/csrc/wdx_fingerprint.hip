@@ -1898,7 +1898,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         static LdsAttr attr_l1[3], attr_huge[3];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
-        if (with_big0 || with_big1 || (approx && chain))
+        if (with_big0 || with_big1 || with_stream || (approx && chain))
             if (int rc = attr_huge[combo - 1].ensure(kern_ls, flds2)) return rc;
         if (with_big0) {
             // 11 % of RNA004 adapter windows are longer than 5120 samples: a grid for a quarter of the batch, one
@@ -1924,23 +1924,33 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // windows of 6145 .. 16384 samples (RNA002: max_obs_trace + 2 * padding = 15 200): their clip bounds by one
             // workgroup per list entry (samples in LDS), then the streaming form of the fast body -- its LDS is the peak
             // list plus two tile buffers, whatever the window length: four workgroups per CU up to 12 288 samples, three
-            // up to 16 384.  One workgroup per entry; the list's length is only known on the device, so the grid covers
-            // the batch (a workgroup past the list's end leaves at once).  Doubts and refusals go to the exact kernel.
+            // up to 16 384.  One workgroup per entry; the list's length is only known on the device.  With windows beyond
+            // 8192 samples in the batch (RNA002-length reads: every read is on this list) the grids cover the batch; up to
+            // 8192 the long windows are a tail of the batch (687 of 10 M synthetic RNA004 reads) and the grids cover a
+            // sixteenth of it -- a workgroup past the list's end leaves at once, but 10 M of them cost a millisecond per
+            // launch -- with the striding 8192-sample kernel behind them for whatever lies beyond.  Doubts and refusals go
+            // to the exact kernel.
             const int scap = max_len <= 8192 ? 8192 : (max_len <= 12288 ? 12288 : 16384);
             const int capPs = filt ? 1024 : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
             static LdsAttr attr_cb, attr_st[3];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
+            const int64_t g5 = scap == 8192 ? std::min<int64_t>(n_reads, std::max<int64_t>(4096, n_reads / 16)) : n_reads;
             const int64_t max_slice = launch_slice_limit(1ll << 22);
-            for (int64_t base = 0; base < n_reads; base += max_slice) {
+            for (int64_t base = 0; base < g5; base += max_slice) {
                 ClipBlockArgs CB{A, clip, count + 4, big2, scap};
                 CB.a.block_base = base;
-                hipLaunchKernelGGL(clip_bounds_block_kernel, dim3((unsigned)std::min<int64_t>(max_slice, n_reads - base)), dim3(FB),
+                hipLaunchKernelGGL(clip_bounds_block_kernel, dim3((unsigned)std::min<int64_t>(max_slice, g5 - base)), dim3(FB),
                                    lds_cb, stream, CB);
             }
             FastArgs F5{A, 16384, capPs, count, list, nullptr, nullptr, count + 4, big2, 0u, nullptr, nullptr, clip};
-            launch_sliced(kern_st, F5, n_reads, lds_st, false);
+            launch_sliced(kern_st, F5, g5, lds_st, false);
+            if (g5 < n_reads) {
+                FastArgs F5b{A, capF2, capP2f, count, list, nullptr, nullptr, count + 4, big2, (unsigned)g5, F.retry_count,
+                             F.retry_list, nullptr};
+                hipLaunchKernelGGL(kern_ls, dim3((unsigned)grid), dim3(FB), flds2f, stream, F5b);
+            }
         }
         if (approx && chain) {
             // about 2 reads in 1000: a grid for 1/64 of the batch on the 6144-sample instantiation with exact scores
