@@ -560,11 +560,11 @@ def secondary_regimes(device):
     # packed staging, only the windows cross the bus; feeder: ONE GPU-facing process, P producer processes fill a shared
     # page-locked ring -- always with the producers' own 40 MB fill per minibatch, like "pipe refill")
     # (most telling first: the leg stops launching once 20 s are spent and says which configurations it skipped)
-    for mode, refill, P, jit in (("sync", False, 16, 0), ("sync", False, 4, 0), ("pipe", False, 1, 2900),
-                                 ("feeder", True, 16, 2900), ("pipe", True, 16, 2900), ("feeder", True, 4, 2900)):
-        key = "%s%s%s_P%d" % (mode, "_refill" if (refill and mode != "feeder") else "", "_jitter" if jit else "", P)
+    for mode, refill, P, jit in (("feeder", False, 16, 0), ("sync", False, 16, 0), ("sync", False, 4, 0), ("pipe", False, 1, 2900),
+                                 ("feeder", True, 16, 2900), ("feeder", False, 4, 0)):
+        key = "%s%s%s_P%d" % (mode, "_refill" if refill else "", "_jitter" if jit else "", P)
         cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
-               "--seconds", "1.5", "--jitter", str(jit)] + (["--refill"] if (refill and mode != "feeder") else [])
+               "--seconds", "1.5", "--jitter", str(jit)] + (["--refill"] if refill else [])
         if time.perf_counter() - t_hw > 20.0:   # the leg's budget: the rest is skipped, and says so
             hw[key] = {"skipped": "leg budget of 20 s spent"}
             continue
@@ -580,8 +580,9 @@ def secondary_regimes(device):
                     "included) through fingerprint + DTW (110-pt x 10 refs) + call; sync = sig_proc.demux_batch on a pageable "
                     "array, pipe = MinibatchPipeline (page-locked buffers, wdx_demux_submit / wdx_demux_wait); refill = the "
                     "worker copies a fresh minibatch into the buffer before every call; jitter = adapter_start ~ U{100..3000} per "
-                    "read (rows carry whole reads; page-locked rows then go through the packed staging); feeder = one GPU-facing "
-                    "process with 8 slots + P producer processes filling a shared page-locked ring",
+                    "read (rows carry whole reads; page-locked rows then go through the packed staging); feeder = warpdemux_amd.feeder.Feeder: one "
+                    "GPU-facing process serving a shared-memory ring of 8 minibatch slots (wdx_feeder_serve), the P workers call "
+                    "feeder.demux_batch like the sync mode calls sig_proc.demux_batch (wdx_feeder_demux: no context, no HIP call)",
         "host_cpus": effective_cores(), **hw,
         "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
         "parity": bool(good) and all(v.get("parity") is True for v in hw.values() if "skipped" not in v)}

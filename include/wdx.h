@@ -270,6 +270,32 @@ int wdx_host_free(void *p);
 int wdx_host_register(void *p, size_t bytes);
 int wdx_host_unregister(void *p);
 
+/* ---- many worker processes, ONE GPU-facing process (replaces the reference's per-worker GPU use in its `-j 8..16`
+ *      forked workers, file_proc.py:1197-1243, 380-454).  Sixteen HIP processes on one device run at 40 % of the rate of
+ *      four; one process that owns the context and keeps up to WDX_MAX_SLOTS minibatches in flight for everybody does not
+ *      have that problem.  The ring lives in shared memory the caller maps in every process (parent: create + init BEFORE
+ *      the fork; Python: warpdemux_amd.feeder.Feeder):
+ *        wdx_feeder_ring_bytes / _init   size and lay out the ring: n_slots (<= WDX_FEEDER_MAX_RING_SLOTS) minibatches of at
+ *                                        most max_reads x max_stride float32 samples, distances to n_refs references.
+ *                                        (A worker holds its ring slot while it copies 40 MB in and the results out; the
+ *                                        feeder keeps at most WDX_MAX_SLOTS of the READY ones in flight on the device.)
+ *        wdx_feeder_serve(ctx, ring, p)  the GPU-facing process: page-locks the ring and serves it until wdx_feeder_stop --
+ *                                        every READY slot goes through wdx_demux_submit, the oldest in flight through
+ *                                        wdx_demux_wait; the context's resident references (wdx_set_refs) classify
+ *        wdx_feeder_demux(ring, ...)     a worker: wdx_demux_batch's arguments and outputs (bit-identical results), but
+ *                                        no context and NO HIP call -- the minibatch is copied into a free slot, the
+ *                                        worker sleeps on the slot (futex) until the results are there.  n_reads x stride
+ *                                        must fit a slot; WDX_ERR_NO_DEVICE when the feeder has stopped or died
+ *        wdx_feeder_stop(ring)           ends wdx_feeder_serve (it first drains what is in flight) */
+#define WDX_FEEDER_MAX_RING_SLOTS 32
+size_t wdx_feeder_ring_bytes(int32_t n_slots, int64_t max_reads, int64_t max_stride, int64_t n_refs);
+int wdx_feeder_ring_init(void *mem, size_t bytes, int32_t n_slots, int64_t max_reads, int64_t max_stride, int64_t n_refs);
+int wdx_feeder_serve(wdx_ctx *ctx, void *ring, const wdx_seg_params *p);
+int wdx_feeder_demux(void *ring, const float *sig, int64_t n_reads, int64_t stride, const int32_t *a_start,
+                     const int32_t *a_end, const uint8_t *ok, int64_t n_refs, float *dist, int32_t *call, int32_t *status);
+int wdx_feeder_stop(void *ring);
+int wdx_feeder_served(void *ring, int64_t *minibatches);   /* minibatches handed back so far */
+
 /* Live path (BASELINE config 5; N4): every read of one 100 ms chunk round in one call -- the batched form of
  * live_balancing/worker.py:26-96 (segmentation_worker) + :99-131 (classification_worker).  rows[r] points at
  * read r's float32 samples (row_len[r] of them; ragged, caller-owned, only the adapter window

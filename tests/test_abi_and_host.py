@@ -179,3 +179,41 @@ def test_refinement_parameters_validate_like_the_reference():
     seg.consensus_subseq_match_normalization = "zscore"
     with pytest.raises(ValueError, match="not recognized"):
         sig_proc.RefineParams.from_spc(spc, q).to_c()
+
+
+def test_feeder_ring_geometry_and_the_worker_side_without_a_feeder():
+    """wdx_feeder_* (many worker processes, one GPU-facing process): the ring's size and layout, argument checks of the
+    worker-side call, and its answer when no feeder serves the ring -- none of which needs a GPU (the worker side makes no
+    HIP call by design)."""
+    import ctypes as C
+    import mmap
+
+    L = _lib.load()
+    assert L.wdx_feeder_ring_bytes(0, 10, 10, 4) == 0 and L.wdx_feeder_ring_bytes(33, 10, 10, 4) == 0
+    assert L.wdx_feeder_ring_bytes(2, 0, 10, 4) == 0
+    n = L.wdx_feeder_ring_bytes(2, 10, 100, 4)
+    assert n % 4096 == 0 and n >= 4096 + 2 * 10 * 100 * 4
+    m = mmap.mmap(-1, n)
+    base = C.c_void_p(C.addressof(C.c_char.from_buffer(m)))
+    sig = np.zeros((3, 50), np.float32)
+    a = np.zeros(3, np.int32)
+    d = np.zeros((3, 4), np.float32)
+    c = np.zeros(3, np.int32)
+    args = (sig.ctypes.data, 3, 50, a.ctypes.data, a.ctypes.data, None)
+    with pytest.raises(ValueError, match="not an initialised ring"):
+        _lib.check(L.wdx_feeder_demux(base, *args, 4, d.ctypes.data, c.ctypes.data, c.ctypes.data))
+    with pytest.raises(ValueError):
+        _lib.check(L.wdx_feeder_ring_init(base, n - 1, 2, 10, 100, 4))
+    _lib.check(L.wdx_feeder_ring_init(base, n, 2, 10, 100, 4))
+    with pytest.raises(ValueError, match="does not fit"):
+        _lib.check(L.wdx_feeder_demux(base, sig.ctypes.data, 11, 50, a.ctypes.data, a.ctypes.data, None, 4, d.ctypes.data,
+                                      c.ctypes.data, c.ctypes.data))
+    with pytest.raises(ValueError, match="references"):
+        _lib.check(L.wdx_feeder_demux(base, *args, 5, d.ctypes.data, c.ctypes.data, c.ctypes.data))
+    served = C.c_int64(-1)
+    _lib.check(L.wdx_feeder_served(base, C.byref(served)))
+    assert served.value == 0
+    _lib.check(L.wdx_feeder_stop(base))
+    with pytest.raises(_lib.WdxNoDevice, match="feeder"):      # stopped, nobody serves: the worker is told, it does not hang
+        _lib.check(L.wdx_feeder_demux(base, *args, 4, d.ctypes.data, c.ctypes.data, c.ctypes.data))
+    del base

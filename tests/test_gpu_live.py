@@ -444,7 +444,7 @@ def test_packed_staging_of_minibatches_with_jittered_adapter_starts():
 @pytest.mark.timeout(400)
 def test_forked_workers_share_the_gpu_through_pipelines():
     """tools/host_workers.py: 4 forked workers x pipelined 1000-read minibatches on one GPU, oracle-checked."""
-    for mode in ("sync", "pipe"):
+    for mode in ("sync", "pipe", "feeder"):     # feeder: warpdemux_amd.feeder.Feeder (wdx_feeder_serve / wdx_feeder_demux)
         rc, so, se = _run_bounded([sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", "4",
                                    "--mode", mode, "--seconds", "1", "--refill"])
         assert rc == 0, so[-2000:] + se[-2000:]

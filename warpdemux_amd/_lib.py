@@ -48,6 +48,7 @@ EXPORTS = [
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_svm_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
+    "wdx_feeder_ring_bytes", "wdx_feeder_ring_init", "wdx_feeder_serve", "wdx_feeder_demux", "wdx_feeder_stop", "wdx_feeder_served",
 ]
 
 
@@ -252,6 +253,18 @@ def load():
         L.wdx_synth_lengths_dev.argtypes = [vp, u64, i64, i64, i32, vp, vp, vp]
         L.wdx_synth_fill_dev.restype = C.c_int
         L.wdx_synth_fill_dev.argtypes = [vp, u64, i64, i64, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.wdx_feeder_ring_bytes.restype = C.c_size_t
+        L.wdx_feeder_ring_bytes.argtypes = [i32, i64, i64, i64]
+        L.wdx_feeder_ring_init.restype = C.c_int
+        L.wdx_feeder_ring_init.argtypes = [vp, C.c_size_t, i32, i64, i64, i64]
+        L.wdx_feeder_serve.restype = C.c_int
+        L.wdx_feeder_serve.argtypes = [vp, vp, P(SegParamsC)]
+        L.wdx_feeder_demux.restype = C.c_int
+        L.wdx_feeder_demux.argtypes = [vp, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
+        L.wdx_feeder_stop.restype = C.c_int
+        L.wdx_feeder_stop.argtypes = [vp]
+        L.wdx_feeder_served.restype = C.c_int
+        L.wdx_feeder_served.argtypes = [vp, P(i64)]
         if L.wdx_abi_version() != ABI_VERSION:
             raise WdxError("libwdx_hip.so ABI version mismatch")
         _lib = L
