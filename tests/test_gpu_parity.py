@@ -1132,9 +1132,10 @@ def test_launch_chain_lists_longer_than_their_grids():
 
 
 def test_streaming_list_longer_than_its_grid():
-    """Up to 8192 samples the streaming kernels' grids cover a sixteenth of the batch (at least 4096 entries) and the
-    striding 8192-sample kernel takes the list entries beyond: a batch in which EVERY window has 6200 .. 8000 samples
-    (4 608 list entries) still matches the oracle, on either side of the grid's end."""
+    """In batches of more than 2 M reads whose windows stay below 8192 samples the streaming kernels' grids cover a
+    sixteenth of the batch and the striding 8192-sample kernel takes the list entries beyond (WDX_OPT_MAX_LAUNCH_SLICE
+    selects that form for a batch of any size): a batch in which EVERY window has 6200 .. 8000 samples (4 608 list
+    entries, 288 of them inside the grid) still matches the oracle, on either side of the grid's end."""
     rng = np.random.default_rng(78)
     n, stride = 4608, 8064
     mb = np.full((n, stride), np.nan, dtype=np.float32)
@@ -1146,7 +1147,10 @@ def test_streaming_list_longer_than_its_grid():
     a_s = np.zeros(n, dtype=np.int32)
     a_e = lens.astype(np.int32)
     ph, po = sig_proc.SegParams(padding=0, barcode_num_events=25), orc.SegParams(padding=0, barcode_num_events=25)
-    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    with _option(_lib.OPT_MAX_LAUNCH_SLICE, 1_000_000):
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)
+    plain = sig_proc.fingerprint_batch(mb, a_s, a_e, ph)         # (every entry inside the grid)
+    assert np.array_equal(fb.status, plain.status) and _same(fb.fpt, plain.fpt) and _same(fb.dwell, plain.dwell)
     sub = np.concatenate([np.arange(0, 4000, 16), np.arange(4000, n, 3)])   # (list order is arbitrary: sample everywhere)
     fpt, dwell, stats, status = orc.fingerprint_batch(mb[sub], a_s[sub], a_e[sub], po)
     assert np.array_equal(fb.status[sub], status) and (status == 0).mean() > 0.98

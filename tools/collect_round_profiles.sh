@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r05a}
+TAG=${1:-r05d}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -23,5 +23,13 @@ bash tools/dev/rfstats.sh > gpurun_out/${TAG}_refine_kernel_trace.txt 2>&1
 python3 tools/pmc_kernel.py refine_tail_kernel,refine_match_wave,fingerprint_list_kernel -- python3 $PWD/tools/bench_refine.py 32768 > gpurun_out/${TAG}_refine_sq_counters.txt 2>&1
 python3 bench.py --leg shipped_model_e2e > gpurun_out/${TAG}_shipped_model_e2e.json 2> /dev/null
 for t in "110 6 12" "110 15 30" "120 9 18"; do python3 tools/profile_exact.py $t 65536 >> gpurun_out/${TAG}_exact_kernel_triples.txt 2>&1; done
+for t in "110 15 30 65536 2.5" "110 15 30 262144 1.0" "120 9 18 262144 1.0"; do
+    n=$(echo $t | tr ' .' '__'); tools/dev/kstats.sh ${TAG}_triple_$n python3 $PWD/tools/bench_triple.py $t 5 >> gpurun_out/${TAG}_triples_kernel_split.txt 2>&1
+done
+for w in 4 16; do python3 tools/host_workers.py --workers $w --mode feeder --seconds 2 >> gpurun_out/${TAG}_host_workers.txt 2>&1; python3 tools/host_workers.py --workers $w --mode sync --seconds 2 >> gpurun_out/${TAG}_host_workers.txt 2>&1; done
+# the C4 launch path on this one-GPU box (eight ranks share the device, host collectives): a same-tree reference for the
+# first real 8-GPU run's per_rank_ms_per_step / rccl_ranks
+WDX_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 8 --reads 20000 --steps 2 --warmup 1 --no-cpu --no-secondary > gpurun_out/${TAG}_c4_gloo_8ranks_one_gpu.json 2> gpurun_out/${TAG}_c4_gloo.err
+rm -f gpurun_out/${TAG}_triple_*_kstats.log gpurun_out/${TAG}_triple_*_kernel_stats.csv
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_traffic gpurun_out/${TAG}_sq gpurun_out/phase_pmc
 ls -la gpurun_out | grep ${TAG}

@@ -1926,17 +1926,19 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // list plus two tile buffers, whatever the window length: four workgroups per CU up to 12 288 samples, three
             // up to 16 384.  One workgroup per entry; the list's length is only known on the device.  With windows beyond
             // 8192 samples in the batch (RNA002-length reads: every read is on this list) the grids cover the batch; up to
-            // 8192 the long windows are a tail of the batch (687 of 10 M synthetic RNA004 reads) and the grids cover a
-            // sixteenth of it -- a workgroup past the list's end leaves at once, but 10 M of them cost a millisecond per
-            // launch -- with the striding 8192-sample kernel behind them for whatever lies beyond.  Doubts and refusals go
-            // to the exact kernel.
+            // 8192 the long windows are a tail of the batch (687 of 10 M synthetic RNA004 reads) and, for batches of more
+            // than 2 M reads, the grids cover a sixteenth of it -- a workgroup past the list's end leaves at once, but 10 M of
+            // them cost a millisecond per launch -- with the striding 8192-sample kernel behind them for whatever lies
+            // beyond.  Doubts and refusals go to the exact kernel.
             const int scap = max_len <= 8192 ? 8192 : (max_len <= 12288 ? 12288 : 16384);
             const int capPs = filt ? 1024 : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
             static LdsAttr attr_cb, attr_st[3];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
-            const int64_t g5 = scap == 8192 ? std::min<int64_t>(n_reads, std::max<int64_t>(4096, n_reads / 16)) : n_reads;
+            // (WDX_OPT_MAX_LAUNCH_SLICE, the tests' switch for the multi-launch paths, also selects the bounded grids)
+            const int64_t g5 = (scap == 8192 && (n_reads > (1ll << 21) || knobs.max_launch_slice > 0))
+                                   ? std::max<int64_t>(1, n_reads / 16) : n_reads;
             const int64_t max_slice = launch_slice_limit(1ll << 22);
             for (int64_t base = 0; base < g5; base += max_slice) {
                 ClipBlockArgs CB{A, clip, count + 4, big2, scap};
