@@ -1893,7 +1893,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const size_t flds1 = fast_lds_bytes(capF1, capP1, nbt), flds2 = fast_lds_bytes(capF2, capP2, nbt);
         // the same kernels behind filtered appends (the approximate-keys launches; the exact-scores retry keeps the long
         // lists): 512 entries -> five workgroups per CU at 6144 samples, four at 8192
-        const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 512 : capP2;
+        // (the striding 8192-sample kernel is NOT an EXT instantiation: its in-kernel medians put their 2112-word histogram
+        // where the peak list will be, so its list region must hold 8448 bytes -- 768 entries, not 512)
+        const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 768 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
         static LdsAttr attr_l1[3], attr_huge[3];
         if (with_big0 || (approx && chain))
