@@ -1131,6 +1131,34 @@ def test_launch_chain_lists_longer_than_their_grids():
     assert _same(fc.fpt[sub][good], fpt[good]) and _same(fc.dwell[sub][good], dwell[good])
 
 
+def test_accept_less_cpts_runs_on_the_fast_kernels():
+    """segmentation.accept_less_cpts = True (sig_proc.py:185-188: fewer than num_events peaks -> fewer events instead of
+    a failure) used to send the whole batch to the exact kernel.  Now the fast kernels take it and hand over only the
+    reads it concerns.  Windows of 1 270 .. 1 700 samples (the shortest that keep the configured width 12) have ~100 .. 140
+    kept peaks: some below num_events = 110, so both outcomes occur; everything against the oracle, both settings."""
+    rng = np.random.default_rng(79)
+    n, stride = 3072, 4800
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    lens = np.concatenate([rng.integers(1270, 1701, 2048), rng.integers(3000, 4700, n - 2048)])
+    for i, ln in enumerate(lens):
+        ev = int(rng.integers(10, 30))
+        lvl = np.repeat(rng.normal(85, 14, ln // ev + 1), ev)[:ln]
+        mb[i, :ln] = (lvl + rng.normal(0, 2, ln)).astype(np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = lens.astype(np.int32)
+    seen = {}
+    for acc in (False, True):
+        kw = dict(padding=0, barcode_num_events=25, accept_less_cpts=acc)
+        fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+        assert np.array_equal(fb.status, status)
+        ok = status == 0
+        assert _same(fb.fpt[ok], fpt[ok]) and _same(fb.dwell[ok], dwell[ok]) and _same(fb.stats[ok], stats[ok])
+        seen[acc] = status
+    gave_up = (seen[False] != 0) & (seen[True] == 0)      # too few peaks: a failure without the option, a fingerprint with it
+    assert gave_up.sum() > 20 and (seen[False] == 0).sum() > 2000
+
+
 def test_streaming_list_longer_than_its_grid():
     """In batches of more than 2 M reads whose windows stay below 8192 samples the streaming kernels' grids cover a
     sixteenth of the batch and the striding 8192-sample kernel takes the list entries beyond (WDX_OPT_MAX_LAUNCH_SLICE

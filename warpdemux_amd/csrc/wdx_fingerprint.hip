@@ -1753,7 +1753,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     // width other than 12 or a configured distance beyond 9 only a few very short reads would qualify -- sig_proc.py:
     // 526-533 shrinks the parameters for those -- and a launch chain whose main kernel declines nearly every read
     // costs more than it saves: 1.62 against 1.99 M reads/s on the RNA002 triple (110, 15, 30))
-    const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE && !p.accept_less_cpts &&
+    const bool fast_ok = d_ws && p.sig_norm == WDX_NORM_NONE &&   // (accept_less_cpts: the fast kernels hand over the reads it concerns)
                          p.num_events <= kFSeg - 2 && p.barcode_num_events <= p.num_events + 1 &&
                          fast_combo(p) != 0 && (fast_combo(p) == 1 || !d_prof) && cap >= 512 && !knobs.exact_path &&
                          (!rf || (rf->ws && !d_prof && p.num_events + 1 <= 128));
