@@ -1933,7 +1933,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // them cost a millisecond per launch -- with the striding 8192-sample kernel behind them for whatever lies
             // beyond.  Doubts and refusals go to the exact kernel.
             const int scap = max_len <= 8192 ? 8192 : (max_len <= 12288 ? 12288 : 16384);
-            const int capPs = filt ? 1024 : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
+            const int capPs = filt ? (scap == 8192 ? 1024 : (scap == 12288 ? 1280 : 1536))   // (the list from kPeakTauLo up)
+                                   : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
             static LdsAttr attr_cb, attr_st[3];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
