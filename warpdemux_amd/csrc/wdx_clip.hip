@@ -519,6 +519,52 @@ __global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bound
     clip_wave<NPL>(C.a, C.rec, r, C.cap, clip_lds[wave]);
 }
 
+// The reads whose window is longer than the main instantiation takes, listed for the next instantiation AHEAD of the main
+// kernel: one thread per read, one atomic per workgroup of 1024.  Listing them from the main kernel costs one returning atomic per
+// workgroup on a single counter -- 11 ns each once every workgroup of the launch does nothing else (a batch of
+// RNA002-length windows: 0.75 ms per 65 536 reads).  Same predicate as fast_body's (successful detection, window > cap).
+__global__ __launch_bounds__(1024) void route_long_windows_kernel(FpArgs A, int cap, unsigned *big_count, int32_t *big_list) {
+    __shared__ unsigned wcnt[16], wbase;
+    const int64_t r = A.block_base + (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int wave = (int)(threadIdx.x >> 6);
+    bool take = false;
+    if (r < A.n_reads && !(A.ok && !A.ok[r])) {
+        const int64_t row_len = A.row_len ? (int64_t)A.row_len[r] : (A.row_off ? A.row_off[r + 1] - A.row_off[r] : A.stride);
+        int64_t start = (int64_t)A.a_start[r] - A.p.padding;
+        if (start < 0) start = 0;
+        int64_t stop = (int64_t)A.a_end[r] + A.p.padding;
+        if (stop > row_len) stop = row_len;
+        take = stop - start > (int64_t)cap;
+    }
+    // one atomic per WORKGROUP (1024 reads): the counter is one address, and returning atomics on it serialise at ~10 ns
+    const unsigned long long mask = __ballot(take);
+    if ((threadIdx.x & 63) == 0) wcnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wcnt[w];
+        wbase = tot ? atomicAdd(big_count, tot) : 0u;
+    }
+    __syncthreads();
+    if (!take) return;
+    unsigned base = wbase;
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    big_list[base + at] = (int32_t)r;
+}
+
+int launch_route_long_windows(const FpArgs &A, int cap, unsigned *d_count, int32_t *d_list, hipStream_t stream) {
+    FpArgs R = A;
+    const int64_t n_wg = (A.n_reads + 1023) / 1024, max_slice = launch_slice_limit(1ll << 21);
+    for (int64_t base = 0; base < n_wg; base += max_slice) {
+        R.block_base = base * 1024;
+        hipLaunchKernelGGL(route_long_windows_kernel, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)), dim3(1024), 0, stream,
+                           R, cap, d_count, d_list);
+    }
+    WDX_HIP_TRY(hipGetLastError());
+    return WDX_SUCCESS;
+}
+
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
                             hipStream_t stream) {
     if (n_entries <= 0) return WDX_SUCCESS;

@@ -1876,6 +1876,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             // main kernel hands them to the lists before it would look at their record)
             if (main_ev && main_ev->c_first) (void)hipEventRecord(main_ev->c_first, stream);
             if (int rc = launch_clip_bounds(A, clip, capF, stream)) return rc;
+            if (F.big_list) {   // the windows beyond capF go on the main kernel's hand-over list here (one atomic per 64 reads)
+                if (int rc = launch_route_long_windows(A, capF, F.big_count, F.big_list, stream)) return rc;
+                F.routed = 1;
+            }
             if (main_ev && main_ev->c_first) {
                 (void)hipEventRecord(main_ev->c_second, stream);
                 main_ev->c_recorded = true;
@@ -1950,7 +1954,25 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                                    lds_cb, stream, CB);
             }
             FastArgs F5{A, 16384, capPs, count, list, nullptr, nullptr, count + 4, big2, 0u, nullptr, nullptr, clip};
+            // batches of long windows (beyond 8192 samples: the grids cover the batch anyway): a read with a decision inside
+            // the error band, or whose cut does not clear the append filter's threshold, is redone by a second launch of the
+            // same kernel on exact scores with the unfiltered list capacity -- instead of the exact general kernel, which
+            // serves such a window at a twentieth of the rate.  (The 8192-sample list's slots are free: big1 is not in use
+            // when the streaming kernel is.)
+            const bool st_retry = approx && scap > 8192;
+            if (st_retry) {
+                F5.retry_count = count + 2;
+                F5.retry_list = big1;
+            }
             launch_sliced(kern_st, F5, g5, lds_st, false);
+            if (st_retry) {
+                const int capPx = scap == 12288 ? 2520 : 3400;
+                const size_t lds_x = fast_stream_lds_bytes(capPx, nbt);
+                if (int rc = attr_st[combo - 1].ensure(kern_st, lds_x)) return rc;
+                FastArgs F6{A, 16384, capPx, count, list, nullptr, nullptr, count + 2, big1, 0u, nullptr, nullptr, clip};
+                F6.a.exact_scores = 1;
+                launch_sliced(kern_st, F6, n_reads, lds_x, false);
+            }
             if (g5 < n_reads) {
                 FastArgs F5b{A, capF2, capP2f, count, list, nullptr, nullptr, count + 4, big2, (unsigned)g5, F.retry_count,
                              F.retry_list, nullptr};

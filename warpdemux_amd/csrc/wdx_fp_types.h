@@ -108,6 +108,7 @@ __device__ __forceinline__ float key_f32(unsigned k) {
 // A1 for a whole batch ahead of the fast kernels' launch chain (wdx_clip.hip): one ClipRec per read of A; windows of
 // 256 .. cap samples (cap = 4096, 5120 or 6144: the main fast instantiation's) are taken, the others are flagged CLIP_NONE.
 int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t stream);
+int launch_route_long_windows(const FpArgs &A, int cap, unsigned *d_count, int32_t *d_list, hipStream_t stream);
 // the same for the first n_entries entries of a device-side read list (windows up to 6144 samples; reads that already
 // have a record are skipped)
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
