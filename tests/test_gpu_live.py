@@ -254,6 +254,19 @@ def test_forked_workers_create_their_own_contexts():
     assert all(all(w) for w in rec["ok"]), rec
 
 
+def test_feeder_serves_forked_workers_and_reports_its_own_death():
+    """warpdemux_amd.feeder.Feeder (wdx_feeder_*): the parent creates it, a ProcessPoolExecutor's forked workers use the
+    inherited object -- results against the oracle for several minibatch shapes and success flags, argument errors on the
+    worker side, and a worker that calls after the feeder process was killed is told so (WdxNoDevice), it does not hang."""
+    rc, so, se = _run_bounded([sys.executable, os.path.join(ROOT, "tests", "helpers", "feeder_check.py")])
+    assert rc == 0, se[-2000:]
+    rec = json.loads(so.strip().splitlines()[-1])
+    assert len(rec["pids"]) >= 2 and rec["parent"] not in rec["pids"]
+    assert all(all(w) for w in rec["ok"]), rec
+    assert all(e == [True, True] for e in rec["errs"]), rec
+    assert rec["served"] == 16 and rec["after_death"].startswith("told"), rec
+
+
 def test_context_leaves_the_callers_device_alone_and_rejects_use_after_fork_pid():
     import torch
 

@@ -157,6 +157,7 @@ int wdx_feeder_serve(wdx_ctx *ctx, void *ring, const wdx_seg_params *p) {
         }
     }
     __atomic_store_n(&R->server_pid, (int32_t)getpid(), __ATOMIC_RELEASE);
+    const pid_t parent = getppid();   // (the process that created the ring: when it is gone, nobody will stop us)
     const int64_t mr = R->max_reads, nY = R->n_refs;
     // ring slots in flight, oldest first, each on one of the context's WDX_MAX_SLOTS submit / wait slots
     struct Fly { int ring, cslot; } fifo[WDX_MAX_SLOTS];
@@ -184,6 +185,7 @@ int wdx_feeder_serve(wdx_ctx *ctx, void *ring, const wdx_seg_params *p) {
         return rc;
     };
     while (!ld(&R->stop)) {
+        if (getppid() != parent) break;   // orphaned: the parent died without wdx_feeder_stop
         const uint32_t seen = ld(&R->seq);
         bool progressed = false;
         for (uint32_t q = 0; q < R->n_slots && count < WDX_MAX_SLOTS; ++q) {
