@@ -295,6 +295,7 @@ int wdx_feeder_demux(void *ring, const float *sig, int64_t n_reads, int64_t stri
                      const int32_t *a_end, const uint8_t *ok, int64_t n_refs, float *dist, int32_t *call, int32_t *status);
 int wdx_feeder_stop(void *ring);
 int wdx_feeder_served(void *ring, int64_t *minibatches);   /* minibatches handed back so far */
+int wdx_feeder_alive(void *ring);   /* 1 while a feeder process serves the ring, 0 once it has stopped or died (< 0: error) */
 
 /* Live path (BASELINE config 5; N4): every read of one 100 ms chunk round in one call -- the batched form of
  * live_balancing/worker.py:26-96 (segmentation_worker) + :99-131 (classification_worker).  rows[r] points at

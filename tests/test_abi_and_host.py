@@ -213,6 +213,7 @@ def test_feeder_ring_geometry_and_the_worker_side_without_a_feeder():
     served = C.c_int64(-1)
     _lib.check(L.wdx_feeder_served(base, C.byref(served)))
     assert served.value == 0
+    assert L.wdx_feeder_alive(base) == 0          # nobody serves this ring
     _lib.check(L.wdx_feeder_stop(base))
     with pytest.raises(_lib.WdxNoDevice, match="feeder"):      # stopped, nobody serves: the worker is told, it does not hang
         _lib.check(L.wdx_feeder_demux(base, *args, 4, d.ctypes.data, c.ctypes.data, c.ctypes.data))

@@ -48,7 +48,7 @@ EXPORTS = [
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_svm_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
-    "wdx_feeder_ring_bytes", "wdx_feeder_ring_init", "wdx_feeder_serve", "wdx_feeder_demux", "wdx_feeder_stop", "wdx_feeder_served",
+    "wdx_feeder_ring_bytes", "wdx_feeder_ring_init", "wdx_feeder_serve", "wdx_feeder_demux", "wdx_feeder_stop", "wdx_feeder_served", "wdx_feeder_alive",
 ]
 
 
@@ -265,6 +265,8 @@ def load():
         L.wdx_feeder_stop.argtypes = [vp]
         L.wdx_feeder_served.restype = C.c_int
         L.wdx_feeder_served.argtypes = [vp, P(i64)]
+        L.wdx_feeder_alive.restype = C.c_int
+        L.wdx_feeder_alive.argtypes = [vp]
         if L.wdx_abi_version() != ABI_VERSION:
             raise WdxError("libwdx_hip.so ABI version mismatch")
         _lib = L

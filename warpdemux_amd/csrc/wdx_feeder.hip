@@ -128,6 +128,13 @@ int wdx_feeder_stop(void *ring) {
     return WDX_SUCCESS;
 }
 
+int wdx_feeder_alive(void *ring) {
+    FeederRing *R = (FeederRing *)ring;
+    if (int rc = ring_check(R)) return rc;
+    const int32_t pid = __atomic_load_n(&R->server_pid, __ATOMIC_ACQUIRE);
+    return (!ld(&R->stop) && pid > 0 && !(kill(pid, 0) != 0 && errno == ESRCH)) ? 1 : 0;
+}
+
 int wdx_feeder_served(void *ring, int64_t *minibatches) {
     FeederRing *R = (FeederRing *)ring;
     if (int rc = ring_check(R)) return rc;

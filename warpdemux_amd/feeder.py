@@ -41,6 +41,8 @@ def _serve(shm_name: str, refs, window, penalty, pc_bytes: bytes, device: int, r
                                   float(penalty) if penalty else 0.0))
         pc = _lib.SegParamsC.from_buffer_copy(pc_bytes)
         base = C.addressof(C.c_char.from_buffer(shm.buf))
+        # (wdx_feeder_serve announces itself in the ring -- server_pid -- once the ring is page-locked; the parent polls
+        # wdx_feeder_alive after this event)
         ready.set()
         _lib.check(L.wdx_feeder_serve(ctx.handle, C.c_void_p(base), C.byref(pc)))
         ctx.close()
@@ -90,7 +92,13 @@ class Feeder:
         self._proc = ctx.Process(target=_serve, args=(self._shm.name, refs, window, penalty, bytes(pc), int(device), ready),
                                  daemon=True)
         self._proc.start()
-        if not ready.wait(start_timeout) or not self._proc.is_alive():
+        import time
+
+        up = ready.wait(start_timeout)
+        t_end = time.monotonic() + 30.0
+        while up and self._proc.is_alive() and self.L.wdx_feeder_alive(C.c_void_p(self._base)) != 1 and time.monotonic() < t_end:
+            time.sleep(0.002)      # context, references, page-locking the ring: the feeder is up when it says so in the ring
+        if not up or not self._proc.is_alive() or self.L.wdx_feeder_alive(C.c_void_p(self._base)) != 1:
             self.close()
             raise _lib.WdxError("the feeder process did not come up (see its stderr)")
 
@@ -113,6 +121,10 @@ class Feeder:
         _lib.check(self.L.wdx_feeder_demux(C.c_void_p(self._base), _lib.ptr(sig), n, stride, _lib.ptr(a_s), _lib.ptr(a_e),
                                            _lib.ptr(ok), self.nY, _lib.ptr(dist), _lib.ptr(call), _lib.ptr(status)))
         return DemuxBatch(status, call, dist, None)
+
+    def alive(self) -> bool:
+        """True while the feeder process serves the ring."""
+        return self._base is not None and self.L.wdx_feeder_alive(C.c_void_p(self._base)) == 1
 
     def served(self) -> int:
         v = C.c_int64(0)
