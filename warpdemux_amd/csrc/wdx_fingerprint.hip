@@ -2020,9 +2020,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             unsigned c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             WDX_HIP_TRY(hipMemcpyAsync(c, count, 32, hipMemcpyDeviceToHost, stream));
             WDX_HIP_TRY(hipStreamSynchronize(stream));
-            fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u to the 8192-sample list kernel, %u to the "
+            // (counter 2 is the 8192-sample list when the streaming kernel is not in the chain, else the streaming kernel's
+            // own exact-scores retry list)
+            fprintf(stderr, "[wdx] of %lld reads: %u beyond the main instantiation, %u %s, %u to the "
                             "streaming kernel, %u redone with exact scores, %u on the exact general kernel\n", (long long)n_reads,
-                    c[1], c[2], c[4], c[3], c[0]);
+                    c[1], c[2], with_stream ? "redone by the streaming kernel on exact scores" : "to the 8192-sample list kernel",
+                    c[4], c[3], c[0]);
             if (rf)
                 fprintf(stderr, "[wdx] refinement: %u reads back from the tail kernel to the exact kernel (%u for a run of equal scores across a "
                                 "tile's end, %u beyond the peak list)\n", c[5], c[6], c[7]);
