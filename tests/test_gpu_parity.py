@@ -396,7 +396,9 @@ def test_long_window_golden_vectors(golden_dir):
             assert fb.status[i] == 0 and _same(fb.fpt[i], g[f"fpt_{k}"]) and _same(fb.dwell[i], g[f"dwell_{k}"])
 
 
-@pytest.mark.parametrize("triple", [(110, 15, 30), (120, 9, 18), (110, 9, 30), (60, 17, 30), (110, 2, 18)])
+@pytest.mark.parametrize("triple", [(110, 15, 30), (120, 9, 18), (110, 9, 30), (60, 17, 30), (110, 2, 18),
+                                    # round 5: the other multiples of six (NBT = 2 instantiations like the RNA002 triple's)
+                                    (110, 3, 6), (110, 6, 6), (110, 12, 24), (90, 17, 24), (100, 17, 36), (110, 8, 36)])
 def test_fast_kernels_of_the_other_shipped_triples(triple):
     """The fast kernels' instantiations for window widths 18 and 30 (tRNA and RNA002 triples; suppression reach up
     to d = 17): synthetic RNA004-like reads, ADC-quantised reads (ties, plateaus -> exact-score tiles, retries) and
@@ -423,7 +425,7 @@ def test_fast_kernels_of_the_other_shipped_triples(triple):
 
 
 @pytest.mark.parametrize("max_slice", [0, 700])     # 700: every launch of the chain cut into slices (block_base != 0)
-@pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18)])
+@pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18), (110, 12, 24), (110, 17, 36), (110, 4, 6)])
 def test_long_windows_in_large_batches_vs_oracle(triple, max_slice):
     """3 000 reads whose windows straddle every capacity edge (5 120 / 6 144 / 8 192 / 11 200 / 16 384) through the
     launch chain: windows of 8 193 .. 16 384 samples take the streaming fast kernel, and what it declines beyond 11 200

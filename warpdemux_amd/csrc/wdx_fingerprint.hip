@@ -1678,11 +1678,18 @@ int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 40 * (n_reads
 //   3: W = 30, d <= 17 (RNA002 triple: 110, 15, 30)
 // 2 runs the 5120-sample instantiation as main kernel for large batches (then 6144 and 8192 behind it, like 1); 3 the
 // 6144-sample one, and the 8192-sample one for longer windows and retries.
+//   4 .. 6: W = 6 / 24 / 36, d <= 17 (round 5: the other multiples of the tile's six positions per lane -- configurations
+//           nobody ships, but `--export segmentation.running_stat_width=...` is one flag away, and the exact kernel
+//           behind this gate runs at a fifteenth of the rate); instantiated like 3 (NBT = 2, 6144-sample main kernel)
+//   12 and 18 with 9 < d <= 17 take the exact kernel as before.
 static int fast_combo(const wdx_seg_params &p) {
     if (p.min_obs_per_base < 1) return 0;
     if (p.running_stat_width == 12 && p.min_obs_per_base <= 9) return 1;
     if (p.running_stat_width == 18 && p.min_obs_per_base <= 9) return 2;
     if (p.running_stat_width == 30 && p.min_obs_per_base <= 17) return 3;
+    if (p.running_stat_width == 6 && p.min_obs_per_base <= 17) return 4;
+    if (p.running_stat_width == 24 && p.min_obs_per_base <= 17) return 5;
+    if (p.running_stat_width == 36 && p.min_obs_per_base <= 17) return 6;
     return 0;
 }
 
@@ -1776,11 +1783,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool large_batch = n_reads >= chain_min;
         const bool approx = large_batch && !knobs.fast_exact_scores;
         const int combo = fast_combo(p);
-        const int nbt = combo == 3 ? 2 : 1;
+        const int nbt = combo >= 3 ? 2 : 1;
         int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
         if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
         if (combo == 2) capF = large_batch ? 5120 : 6144;  // width 18: five workgroups per CU too (91 VGPRs)
-        if (combo == 3) capF = 6144;  // width 30 / reach 17: 115 VGPRs, four waves per SIMD either way
+        if (combo >= 3) capF = 6144;  // width 30 / reach 17 (and the round-5 widths): 115 VGPRs, four waves per SIMD either way
         // (LDS is allocated in 1280-byte granules: five workgroups per CU need <= 32 000 B each, four <= 40 960 B --
         // hipOccupancyMaxActiveBlocksPerMultiprocessor does not know and reports five at 32 640 B)
         // Large batches: the clip bounds of the MAIN kernel's reads are computed ahead of it by clip_bounds_kernel (one wave
@@ -1828,6 +1835,15 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
         void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
         int slot = 0;
+        // (the NBT = 2 widths: one set of four kernels each)
+        auto wide_set = [&](auto fw_t) {
+            constexpr int FWx = decltype(fw_t)::value;
+            kern = ext ? fingerprint_fast_kernel<kNptLarge, false, FWx, 2, true> : fingerprint_fast_kernel<kNptLarge, false, FWx, 2, false>;
+            kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, FWx, 2>;
+            kern_ls = fingerprint_fast_list_kernel<kNptHuge, FWx, 2>;
+            kern_st = fingerprint_fast_stream_kernel<FWx, 2>;
+            slot = 2;
+        };
         if (combo == 2) {
             kern = capF == 5120 ? fingerprint_fast_kernel<kNptMid, false, 18, 1, true>
                                 : (ext ? fingerprint_fast_kernel<kNptLarge, false, 18, 1, true>
@@ -1836,10 +1852,13 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, 18, 1>;
             slot = capF == 5120 ? 1 : 2;
         } else if (combo == 3) {
-            kern = ext ? fingerprint_fast_kernel<kNptLarge, false, 30, 2, true> : fingerprint_fast_kernel<kNptLarge, false, 30, 2, false>;
-            kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 30, 2>;
-            kern_ls = fingerprint_fast_list_kernel<kNptHuge, 30, 2>;
-            slot = 2;
+            wide_set(std::integral_constant<int, 30>{});
+        } else if (combo == 4) {
+            wide_set(std::integral_constant<int, 6>{});
+        } else if (combo == 5) {
+            wide_set(std::integral_constant<int, 24>{});
+        } else if (combo == 6) {
+            wide_set(std::integral_constant<int, 36>{});
         } else if (capF == 4096) {
             kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptSmall, true, kFW, 1, true> : fingerprint_fast_kernel<kNptSmall, false, kFW, 1, true>)
                        : (d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>);
@@ -1851,7 +1870,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
             slot = 2;
         }
-        static LdsAttr attr_fast[3][12];
+        static LdsAttr attr_fast[6][12];
         if (int rc = attr_fast[combo - 1][(ext ? 6 : 0) + (d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
@@ -1901,7 +1920,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // where the peak list will be, so its list region must hold 8448 bytes -- 768 entries, not 512)
         const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 768 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
-        static LdsAttr attr_l1[3], attr_huge[3];
+        static LdsAttr attr_l1[6], attr_huge[6];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
         if (with_big0 || with_big1 || with_stream || (approx && chain))
@@ -1940,7 +1959,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int capPs = filt ? (scap == 8192 ? 1024 : (scap == 12288 ? 1280 : 1536))   // (the list from kPeakTauLo up)
                                    : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
-            static LdsAttr attr_cb, attr_st[3];
+            static LdsAttr attr_cb, attr_st[6];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
             // (WDX_OPT_MAX_LAUNCH_SLICE, the tests' switch for the multi-launch paths, also selects the bounded grids)
