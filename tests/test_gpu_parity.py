@@ -398,7 +398,8 @@ def test_long_window_golden_vectors(golden_dir):
 
 @pytest.mark.parametrize("triple", [(110, 15, 30), (120, 9, 18), (110, 9, 30), (60, 17, 30), (110, 2, 18),
                                     # round 5: the other multiples of six (NBT = 2 instantiations like the RNA002 triple's)
-                                    (110, 3, 6), (110, 6, 6), (110, 12, 24), (90, 17, 24), (100, 17, 36), (110, 8, 36)])
+                                    (110, 3, 6), (110, 6, 6), (110, 12, 24), (90, 17, 24), (100, 17, 36), (110, 8, 36),
+                                    (110, 12, 12), (120, 15, 18)])      # the shipped widths with a reach beyond 9
 def test_fast_kernels_of_the_other_shipped_triples(triple):
     """The fast kernels' instantiations for window widths 18 and 30 (tRNA and RNA002 triples; suppression reach up
     to d = 17): synthetic RNA004-like reads, ADC-quantised reads (ties, plateaus -> exact-score tiles, retries) and
@@ -1266,7 +1267,7 @@ def test_fingerprint_randomised_configs_and_signal_styles(seed):
     ok = (rng.uniform(size=n) > 0.04).astype(np.uint8)
     kw = dict(padding=int(rng.choice([0, 30, 100])), outlier_thresh=float(rng.choice([3.0, 5.0, 8.0])),
               num_events=int(rng.choice([60, 110, 120])), min_obs_per_base=int(rng.choice([2, 3, 6, 9, 15])),
-              running_stat_width=int(rng.choice([12, 12, 12, 10, 18, 30])),
+              running_stat_width=int(rng.choice([12, 12, 12, 10, 18, 30, 6, 24, 36])),
               seg_norm=str(rng.choice(["mean", "median", "none"])))
     kw["barcode_num_events"] = int(rng.choice([10, 25, kw["num_events"]]))
     ph, po = sig_proc.SegParams(**kw), orc.SegParams(**kw)

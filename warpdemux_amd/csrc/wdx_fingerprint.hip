@@ -1681,7 +1681,7 @@ int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 40 * (n_reads
 //   4 .. 6: W = 6 / 24 / 36, d <= 17 (round 5: the other multiples of the tile's six positions per lane -- configurations
 //           nobody ships, but `--export segmentation.running_stat_width=...` is one flag away, and the exact kernel
 //           behind this gate runs at a fifteenth of the rate); instantiated like 3 (NBT = 2, 6144-sample main kernel)
-//   12 and 18 with 9 < d <= 17 take the exact kernel as before.
+//   7, 8: W = 12 / 18 with 9 < d <= 17: the same, for the shipped widths with a longer suppression reach.
 static int fast_combo(const wdx_seg_params &p) {
     if (p.min_obs_per_base < 1) return 0;
     if (p.running_stat_width == 12 && p.min_obs_per_base <= 9) return 1;
@@ -1690,6 +1690,8 @@ static int fast_combo(const wdx_seg_params &p) {
     if (p.running_stat_width == 6 && p.min_obs_per_base <= 17) return 4;
     if (p.running_stat_width == 24 && p.min_obs_per_base <= 17) return 5;
     if (p.running_stat_width == 36 && p.min_obs_per_base <= 17) return 6;
+    if (p.running_stat_width == 12 && p.min_obs_per_base <= 17) return 7;   // (9 < d <= 17: the NBT = 2 form of the width)
+    if (p.running_stat_width == 18 && p.min_obs_per_base <= 17) return 8;
     return 0;
 }
 
@@ -1859,6 +1861,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             wide_set(std::integral_constant<int, 24>{});
         } else if (combo == 6) {
             wide_set(std::integral_constant<int, 36>{});
+        } else if (combo == 7) {
+            wide_set(std::integral_constant<int, 12>{});
+        } else if (combo == 8) {
+            wide_set(std::integral_constant<int, 18>{});
         } else if (capF == 4096) {
             kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptSmall, true, kFW, 1, true> : fingerprint_fast_kernel<kNptSmall, false, kFW, 1, true>)
                        : (d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>);
@@ -1870,7 +1876,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
             slot = 2;
         }
-        static LdsAttr attr_fast[6][12];
+        static LdsAttr attr_fast[8][12];
         if (int rc = attr_fast[combo - 1][(ext ? 6 : 0) + (d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
@@ -1920,7 +1926,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // where the peak list will be, so its list region must hold 8448 bytes -- 768 entries, not 512)
         const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 768 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
-        static LdsAttr attr_l1[6], attr_huge[6];
+        static LdsAttr attr_l1[8], attr_huge[8];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
         if (with_big0 || with_big1 || with_stream || (approx && chain))
@@ -1959,7 +1965,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int capPs = filt ? (scap == 8192 ? 1024 : (scap == 12288 ? 1280 : 1536))   // (the list from kPeakTauLo up)
                                    : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
-            static LdsAttr attr_cb, attr_st[6];
+            static LdsAttr attr_cb, attr_st[8];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
             // (WDX_OPT_MAX_LAUNCH_SLICE, the tests' switch for the multi-launch paths, also selects the bounded grids)
