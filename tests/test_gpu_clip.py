@@ -55,7 +55,7 @@ def _expected(x, params):
     return lo, hi, np.float32(cmax), gate
 
 
-def _rows(rng):
+def _rows(rng, cap=6144):
     rows, tags = [], []
 
     def add(x, tag):
@@ -63,10 +63,11 @@ def _rows(rng):
         tags.append(tag)
 
     for ln in [256, 257, 258, 259, 260, 263, 511, 512, 513, 767, 768, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 3000,
-               4095, 4096, 4097, 4100, 4863, 4864, 4865, 5000, 5117, 5118, 5119, 5120, 5121, 5633, 6143, 6144, 6145, 255, 100]:
+               4095, 4096, 4097, 4100, 4863, 4864, 4865, 5000, 5117, 5118, 5119, 5120, 5121, 5633, 6143, 6144, 6145, 255, 100] + (
+               [] if cap <= 6144 else [7000, 8191, 8192, 8193, 9999, 12287, 12288, 12289, 13056, 13057, 13311, 13312, 13313, 16384]):
         for rep in range(2):
             add(rng.normal(80, 15, ln) + rng.normal(0, 2, ln), "normal")
-    for ln in [300, 1024, 4097, 5120]:
+    for ln in [300, 1024, 4097, 5120] + ([] if cap <= 6144 else [8192, cap - 3]):
         add(np.full(ln, 77.25), "constant")
         add(np.where(rng.random(ln) < 0.5, 70.0, 90.0), "two-valued")
         add(np.round(rng.normal(80, 15, ln) * 4) / 4, "quantised")           # heavy ties: bins with > 64 members
@@ -97,11 +98,11 @@ def _rows(rng):
     return rows, tags
 
 
-@pytest.mark.parametrize("cap", [4096, 5120, 6144])
+@pytest.mark.parametrize("cap", [4096, 5120, 6144, 8192, 13312])   # (the last two: the long-window lists' instantiations)
 @pytest.mark.parametrize("bounds", ["float32", "float64"])
 def test_clip_bounds_kernel_matches_median_mad_bounds_read_by_read(cap, bounds):
     rng = np.random.default_rng(20240 + cap)
-    rows, tags = _rows(rng)
+    rows, tags = _rows(rng, cap)
     params = sig_proc.SegParams(padding=0, outlier_thresh=(np.float64(3.3) if bounds == "float64" else 5.0), clip_bounds=bounds)
     rec = _run(rows, cap, params)
     seen = {}
@@ -132,13 +133,14 @@ def test_clip_bounds_kernel_matches_median_mad_bounds_read_by_read(cap, bounds):
     assert seen.get(("zeros", 1), 0) == 0
 
 
-def test_clip_bounds_kernel_many_random_reads_and_gate_agreement():
-    """2 000 random windows (lengths 256..6144, random offsets / scales / spike rates): wherever the kernel answers, the
+@pytest.mark.parametrize("cap", [6144, 8192, 13312])
+def test_clip_bounds_kernel_many_random_reads_and_gate_agreement(cap):
+    """2 000 random windows (lengths 256..cap, random offsets / scales / spike rates): wherever the kernel answers, the
     bounds are the reference's bit for bit; wherever the gate holds and no sample is negative, it answers."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + cap)
     rows = []
     for i in range(2000):
-        ln = int(rng.integers(256, 6145))
+        ln = int(rng.integers(256 if cap == 6144 else 5000, cap + 1))
         x = rng.normal(rng.uniform(20, 200), rng.uniform(0.5, 30), ln) + rng.normal(0, rng.uniform(0.01, 3), ln)
         k = rng.poisson(ln * rng.choice([0, 0.001, 0.01]))
         if k:
@@ -147,7 +149,7 @@ def test_clip_bounds_kernel_many_random_reads_and_gate_agreement():
             x = np.round(x / 0.1755) * 0.1755     # ADC quantum
         rows.append(x.astype(np.float32))
     params = sig_proc.SegParams(padding=0)
-    rec = _run(rows, 6144, params)
+    rec = _run(rows, cap, params)
     answered = refused_gate_ok = gate_ok = 0
     for x, r in zip(rows, rec):
         assert r["flag"] in (1, 3)

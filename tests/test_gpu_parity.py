@@ -444,11 +444,21 @@ def test_long_windows_in_large_batches_vs_oracle(triple, max_slice):
     for i, ln in enumerate(lens):
         dw = max(12, ln // 135)
         mb[i, :ln] = (np.repeat(rng.normal(80, 15, ln // dw + 1), dw)[:ln] + rng.normal(0, 2, ln)).astype(np.float32)
+    # long windows with flicker spikes below zero (the one-wave clip kernel clamps them away, or leaves the window to the
+    # workgroup kernel behind it), and a few with mostly negative samples (always left to it)
+    for i in range(140, 200):
+        mb[i, rng.integers(0, lens[i], 1 + i % 7)] = -rng.uniform(1, 60, 1 + i % 7).astype(np.float32)
+    for i in range(200, 206):
+        mb[i, :lens[i]] -= np.float32(85.0)
     a_s = np.zeros(n, dtype=np.int32)
     a_e = lens.astype(np.int32)
     kw = dict(padding=0, num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
     with _option(_lib.OPT_MAX_LAUNCH_SLICE, max_slice):
         fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        if w == 30:      # the same with the long windows' clip bounds from the workgroup kernel alone
+            with _option(_lib.OPT_NO_WAVE_CLIP_LONG, 1):
+                fb2 = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+            assert np.array_equal(fb2.status, fb.status) and _same(fb2.fpt, fb.fpt) and _same(fb2.dwell, fb.dwell)
     fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
     big = lens > 16384
     assert (fb.status[big] == 5).all() and big.sum() == 1

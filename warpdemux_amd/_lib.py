@@ -33,6 +33,7 @@ OPT_FAST_CHAIN_MIN_READS = 9
 OPT_EXACT_NO_PEAK_LIST = 10
 OPT_MAX_LAUNCH_SLICE = 11
 OPT_NO_PEAK_FILTER = 12
+OPT_NO_WAVE_CLIP_LONG = 13
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 

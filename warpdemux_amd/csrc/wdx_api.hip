@@ -436,6 +436,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_FAST_CHAIN_MIN_READS: ctx->knobs.fast_chain_min = (int)value; break;
         case WDX_OPT_EXACT_NO_PEAK_LIST: ctx->knobs.exact_no_list = value != 0; break;
         case WDX_OPT_NO_PEAK_FILTER: ctx->knobs.no_peak_filter = value != 0; break;
+        case WDX_OPT_NO_WAVE_CLIP_LONG: ctx->knobs.no_wave_clip_long = value != 0; break;
         case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);
@@ -1506,7 +1507,7 @@ int wdx_selftest_clip_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row
                           void *d_rec, void *stream) {
     WDX_ENTER(ctx);
     if (n_reads < 0 || !p || (n_reads > 0 && (!d_sig || !d_a_start || !d_a_end || !d_rec)) ||
-        (cap != 4096 && cap != 5120 && cap != 6144)) {
+        (cap != 4096 && cap != 5120 && cap != 6144 && cap != 8192 && cap != 13312)) {
         set_error("selftest_clip_dev: bad arguments");
         return WDX_ERR_INVALID;
     }

@@ -40,6 +40,8 @@ struct ClipArgs {
     int cap;  // windows of 256 .. cap samples are taken (cap <= 64 * NPL)
     const unsigned *in_count;  // list form: the first `grid` entries of a device-side read list (else null)
     const int32_t *in_list;
+    int defer;  // 1: a window this kernel cannot decide (negative samples it may not clamp, NaN, infinities) keeps CLIP_NONE --
+                // clip_bounds_block_kernel, which takes any sign, comes after it (the long-window lists)
 };
 
 // xor-exchange inside a row of 16 / a quad (VALU only)
@@ -55,8 +57,9 @@ __device__ __forceinline__ void clip_wave_fence() {
 }
 
 template <int NPL>
-__device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const int64_t r, const int cap, unsigned *lds) {
-    static_assert(NPL % 4 == 0 && NPL * 64 <= 6144, "samples per lane");
+__device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const int64_t r, const int cap, unsigned *lds,
+                                          const bool defer = false) {
+    static_assert(NPL % 4 == 0 && NPL * 64 <= 16384, "samples per lane");
     const int lane = threadIdx.x & 63;
     const wdx_seg_params &P = A.p;
     unsigned *hist = lds;          // kHB words
@@ -142,7 +145,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
         smx = (int)wave_max_u32((unsigned)smx);  // (non-negative integers)
         // -inf / NaN, +inf / NaN, or not one finite non-negative sample -> the exact general kernel
         if (umx >= 0xff800000u || (unsigned)smx >= 0x7f800000u || umn >= 0x7f800000u) {
-            out.flag = CLIP_NAN_NEG;
+            out.flag = defer ? CLIP_NONE : CLIP_NAN_NEG;
             if (lane == 0) recs[r] = out;
             return;
         }
@@ -156,7 +159,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
         }
         umx = (unsigned)smx;
     } else if (umx >= 0x7f800000u) {  // +inf
-        out.flag = CLIP_NAN_NEG;
+        out.flag = defer ? CLIP_NONE : CLIP_NAN_NEG;
         if (lane == 0) recs[r] = out;
         return;
     }
@@ -450,7 +453,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     select(std::false_type{}, odd ? h : h - 1u, umn, umx, m_all, !odd);
     stamp(30);
     if (neg && klo == umn) {  // the median does not lie above the clamped samples: not provably the original's
-        out.flag = CLIP_INEXACT;
+        out.flag = defer ? CLIP_NONE : CLIP_INEXACT;
         if (lane == 0) recs[r] = out;
         return;
     }
@@ -466,7 +469,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     // finite.  A dmax so small that the scale overflows (< 6e-36) is left to the exact kernel.)
     lin_scale = dmax > 0.0f ? (float)(kHB - 1) / dmax : 1.0f;
     if (!(lin_scale > 0.0f && lin_scale < 3.0e38f)) {
-        out.flag = CLIP_INEXACT;
+        out.flag = defer ? CLIP_NONE : CLIP_INEXACT;
         if (lane == 0) recs[r] = out;
         return;
     }
@@ -474,7 +477,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     select(std::true_type{}, odd ? h : h - 1u, 0u, dmaxk, m_all, !odd);
     stamp(24);
     if (neg && (odd ? klo : khi) >= __float_as_uint(dmin_)) {  // the MAD does not lie below the clamped samples' key
-        out.flag = CLIP_INEXACT;
+        out.flag = defer ? CLIP_NONE : CLIP_INEXACT;
         if (lane == 0) recs[r] = out;
         return;
     }
@@ -497,8 +500,11 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     if (lane == 0) recs[r] = out;
 }
 
+// workgroups per CU the register budget admits (512 VGPRs per SIMD lane, NPL of them are the samples)
+constexpr int clip_wgs_per_cu(int npl) { return npl <= 80 ? 4 : (npl <= 128 ? 3 : 2); }
+
 template <int NPL>
-__global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bounds_kernel(ClipArgs C) {
+__global__ __launch_bounds__(kClipWaves * 64, clip_wgs_per_cu(NPL)) void clip_bounds_kernel(ClipArgs C) {
     __shared__ __attribute__((aligned(16))) unsigned clip_lds[kClipWaves][kClipWaveWords];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t r = C.a.block_base + (int64_t)blockIdx.x * kClipWaves + wave;
@@ -509,14 +515,14 @@ __global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bound
 // the reads of a device-side list (the main kernel's hand-overs to the 6144-sample list kernel): one wave per entry,
 // waves past the end of the list and reads that already have their record leave at once
 template <int NPL>
-__global__ __launch_bounds__(kClipWaves * 64, NPL <= 80 ? 4 : 3) void clip_bounds_list_kernel(ClipArgs C) {
+__global__ __launch_bounds__(kClipWaves * 64, clip_wgs_per_cu(NPL)) void clip_bounds_list_kernel(ClipArgs C) {
     __shared__ __attribute__((aligned(16))) unsigned clip_lds[kClipWaves][kClipWaveWords];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t k = C.a.block_base + (int64_t)blockIdx.x * kClipWaves + wave;
     if (k >= (int64_t)*C.in_count) return;
     const int64_t r = C.in_list[k];
     if (C.rec[r].flag != CLIP_NONE) return;
-    clip_wave<NPL>(C.a, C.rec, r, C.cap, clip_lds[wave]);
+    clip_wave<NPL>(C.a, C.rec, r, C.cap, clip_lds[wave], C.defer != 0);
 }
 
 // The reads whose window is longer than the main instantiation takes, listed for the next instantiation AHEAD of the main
@@ -565,27 +571,36 @@ int launch_route_long_windows(const FpArgs &A, int cap, unsigned *d_count, int32
     return WDX_SUCCESS;
 }
 
+// cap 6144 (the hand-overs of the main kernel), or the long-window lists ahead of clip_bounds_block_kernel: 8192 samples at 128
+// registers per lane (three workgroups per CU), 13 312 at 208 (two; the register file ends at 256 per lane)
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
-                            hipStream_t stream) {
+                            hipStream_t stream, int cap, bool defer) {
     if (n_entries <= 0) return WDX_SUCCESS;
-    ClipArgs CA{A, d_rec, 6144, d_count, d_list};
+    if (cap != 6144 && cap != 8192 && cap != kClipWaveLongCap) {
+        set_error("clip_bounds_list_kernel: capacities are 6144, 8192 and 13312 samples");
+        return WDX_ERR_INVALID;
+    }
+    void (*kclip)(ClipArgs) = cap == 6144 ? clip_bounds_list_kernel<96> : (cap == 8192 ? clip_bounds_list_kernel<128> : clip_bounds_list_kernel<kClipWaveLongCap / 64>);
+    ClipArgs CA{A, d_rec, cap, d_count, d_list, defer ? 1 : 0};
     const int64_t n_wg = (n_entries + kClipWaves - 1) / kClipWaves, max_slice = launch_slice_limit(1ll << 22);
     for (int64_t base = 0; base < n_wg; base += max_slice) {
         CA.a.block_base = base * kClipWaves;
-        hipLaunchKernelGGL(clip_bounds_list_kernel<96>, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)),
-                           dim3(kClipWaves * 64), 0, stream, CA);
+        hipLaunchKernelGGL(kclip, dim3((unsigned)std::min<int64_t>(max_slice, n_wg - base)), dim3(kClipWaves * 64), 0, stream, CA);
     }
     WDX_HIP_TRY(hipGetLastError());
     return WDX_SUCCESS;
 }
 
 int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t stream) {
-    if (cap > 6144) {
-        set_error("clip_bounds_kernel takes windows of at most 6144 samples");
+    if (cap > kClipWaveLongCap) {
+        set_error("clip_bounds_kernel takes windows of at most 13312 samples");
         return WDX_ERR_INVALID;
     }
-    void (*kclip)(ClipArgs) = cap <= 4096 ? clip_bounds_kernel<64> : (cap <= 5120 ? clip_bounds_kernel<80> : clip_bounds_kernel<96>);
-    ClipArgs CA{A, d_rec, cap, nullptr, nullptr};
+    // (the chain launches this form up to 6144 samples; beyond, the long-window lists take the list form -- the two long
+    // instantiations are reachable here for the kernel's own tests)
+    void (*kclip)(ClipArgs) = cap <= 4096 ? clip_bounds_kernel<64> : (cap <= 5120 ? clip_bounds_kernel<80> : (cap <= 6144 ? clip_bounds_kernel<96>
+                              : (cap <= 8192 ? clip_bounds_kernel<128> : clip_bounds_kernel<kClipWaveLongCap / 64>)));
+    ClipArgs CA{A, d_rec, cap, nullptr, nullptr, 0};
     const int64_t n_wg = (A.n_reads + kClipWaves - 1) / kClipWaves, max_slice = launch_slice_limit(1ll << 22);
     for (int64_t base = 0; base < n_wg; base += max_slice) {
         CA.a.block_base = base * kClipWaves;

@@ -1972,6 +1972,13 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int64_t g5 = (scap == 8192 && (n_reads > (1ll << 21) || knobs.max_launch_slice > 0))
                                    ? std::max<int64_t>(1, n_reads / 16) : n_reads;
             const int64_t max_slice = launch_slice_limit(1ll << 22);
+            // the one-wave clip kernel first (samples in registers, no barriers: twice the block kernel's rate per sample at
+            // two workgroups of four reads per CU) for the windows its register file holds -- 8192 samples at 128 per lane,
+            // 13 312 at 208; the workgroup kernel then finds a record for those and serves the rest: longer windows, and
+            // the ones the wave form may not decide (negative samples it cannot clamp away)
+            if (!knobs.no_wave_clip_long)
+                if (int rc = launch_clip_bounds_list(A, clip, count + 4, big2, g5, stream, scap == 8192 ? 8192 : kClipWaveLongCap, true))
+                    return rc;
             for (int64_t base = 0; base < g5; base += max_slice) {
                 ClipBlockArgs CB{A, clip, count + 4, big2, scap};
                 CB.a.block_base = base;

@@ -111,8 +111,9 @@ int launch_clip_bounds(const FpArgs &A, ClipRec *d_rec, int cap, hipStream_t str
 int launch_route_long_windows(const FpArgs &A, int cap, unsigned *d_count, int32_t *d_list, hipStream_t stream);
 // the same for the first n_entries entries of a device-side read list (windows up to 6144 samples; reads that already
 // have a record are skipped)
+constexpr int kClipWaveLongCap = 13312;  // the longest window of the one-wave clip kernel (208 samples per lane)
 int launch_clip_bounds_list(const FpArgs &A, ClipRec *d_rec, const unsigned *d_count, const int32_t *d_list, int64_t n_entries,
-                            hipStream_t stream);
+                            hipStream_t stream, int cap = 6144, bool defer = false);
 
 // sqrt and quotient of the t-score without the range scaling of the compiler's general float64
 // expansions.  The iterations are exactly the ones hipcc emits for sqrt() and '/' on gfx950
