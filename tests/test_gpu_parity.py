@@ -425,6 +425,27 @@ def test_fast_kernels_of_the_other_shipped_triples(triple):
     assert np.array_equal(sm.status, status[:700]) and _same(sm.fpt[good[:700]], fpt[:700][good[:700]])
 
 
+@pytest.mark.parametrize("w", range(6, 37))
+def test_every_window_width_and_reach_against_the_oracle(w):
+    """running_stat_width 6 .. 36 x min_obs_per_base 2 .. 17 (any value `--export segmentation.…` can set,
+    config/sig_proc.py:16-70): multiples of six run on the fast kernels (reach <= 17), every other width on the exact
+    general kernel -- the same fingerprints as the oracle either way, through the launch chain of large batches."""
+    spec = synth.SynthSpec(n_barcodes=10)
+    n = 96
+    mb, a_s, a_e, _ = synth.generate_minibatch(spec, 4242 + w, n, 9000)
+    mb[80:] = np.round(mb[80:] / 0.1755) * np.float32(0.1755)         # ADC-quantised rows: ties and plateaus
+    for d in (2, 5, 9, 13, 17):
+        kw = dict(num_events=110, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+        with _chain():
+            fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        assert np.array_equal(fb.status, status), (w, d, np.flatnonzero(fb.status != status))
+        good = status == 0
+        assert _same(fb.fpt[good], fpt[good]) and _same(fb.dwell[good], dwell[good]) and _same(fb.stats[good], stats[good]), (w, d)
+        if d <= 9:
+            assert good.sum() > 0.8 * n, (w, d, int(good.sum()))
+
+
 @pytest.mark.parametrize("max_slice", [0, 700])     # 700: every launch of the chain cut into slices (block_base != 0)
 @pytest.mark.parametrize("triple", [(110, 6, 12), (110, 15, 30), (120, 9, 18), (110, 12, 24), (110, 17, 36), (110, 4, 6)])
 def test_long_windows_in_large_batches_vs_oracle(triple, max_slice):
