@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r05d}
+TAG=${1:-r05f}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -29,7 +29,7 @@ done
 for w in 4 16; do python3 tools/host_workers.py --workers $w --mode feeder --seconds 2 >> gpurun_out/${TAG}_host_workers.txt 2>&1; python3 tools/host_workers.py --workers $w --mode sync --seconds 2 >> gpurun_out/${TAG}_host_workers.txt 2>&1; done
 # the C4 launch path on this one-GPU box (eight ranks share the device, host collectives): a same-tree reference for the
 # first real 8-GPU run's per_rank_ms_per_step / rccl_ranks
-WDX_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 8 --reads 20000 --steps 2 --warmup 1 --no-cpu --no-secondary > gpurun_out/${TAG}_c4_gloo_8ranks_one_gpu.json 2> gpurun_out/${TAG}_c4_gloo.err
+WDX_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 8 --reads 20000 --steps 2 --warmup 1 --no-cpu --no-secondary 2> gpurun_out/${TAG}_c4_gloo.err | grep '^{' > gpurun_out/${TAG}_c4_gloo_8ranks_one_gpu.json
 rm -f gpurun_out/${TAG}_triple_*_kstats.log gpurun_out/${TAG}_triple_*_kernel_stats.csv
 rm -rf gpurun_out/${TAG}_stats gpurun_out/${TAG}_traffic gpurun_out/${TAG}_sq gpurun_out/phase_pmc
 ls -la gpurun_out | grep ${TAG}
