@@ -116,6 +116,7 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_MAX_LAUNCH_SLICE 11    /* fingerprint chain: at most this many workgroups per launch slice (0 = built-in) */
 #define WDX_OPT_NO_PEAK_FILTER 12      /* fast fingerprint kernels: no threshold filter of the peak list (every local maximum) */
 #define WDX_OPT_NO_WAVE_CLIP_LONG 13    /* windows beyond 6144 samples: clip bounds by the workgroup kernel alone (A/B, tests) */
+#define WDX_OPT_NO_CLIP_REUSE 14        /* exact kernel behind the launch chain: recompute the clip bounds (A/B, tests) */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

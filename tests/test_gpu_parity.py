@@ -1124,6 +1124,32 @@ def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch)
             assert _same(ch.fpt, fpt) and _same(ch.dwell, dwell) and _same(ch.stats, stats)
 
 
+def test_exact_kernel_behind_the_chain_takes_the_clip_records():
+    """The exact general kernel behind the launch chain reads the bounds of a CLIP_OK record instead of redoing the two
+    medians (windows with NaN / mostly negative samples have no such record and keep the medians): every read forced
+    onto it (peak lists too small for any read), all signal styles, with the records and without -- the oracle's bits."""
+    rng = np.random.default_rng(4711)
+    styles = ["gauss", "quantised", "integers", "heavy", "negative", "spiky", "flat_runs", "clipped_low"]
+    n, stride = 192, 9000
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        ln = int(rng.choice([300, 1400, 4000, 5000, 5200, 6100, 6200, 7000, 8250, 8800])) + int(rng.integers(-40, 40))
+        mb[i, :ln + 50] = _styled_signal(rng, ln + 50, styles[i % len(styles)])
+        a_s[i], a_e[i] = 20, ln
+    mb[7, 1000] = np.nan
+    mb[15, 2000] = np.inf
+    kw = dict(padding=20, barcode_num_events=25)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+    assert (status == 0).sum() > 0.5 * n
+    for reuse_off in (0, 1):
+        with _chain(), _option(_lib.OPT_FAST_PEAK_CAP, 64), _option(_lib.OPT_NO_CLIP_REUSE, reuse_off):
+            fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        assert np.array_equal(fb.status, status), (reuse_off, np.flatnonzero(fb.status != status))
+        assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats), reuse_off
+
+
 def test_launch_chain_lists_longer_than_their_grids():
     """The per-entry list kernels are launched with grids sized for the expected share of a batch (a quarter for
     windows beyond the main instantiation, 1/64 -- at least 1024 -- for exact-score retries); entries beyond the grid

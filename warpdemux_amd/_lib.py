@@ -34,6 +34,7 @@ OPT_EXACT_NO_PEAK_LIST = 10
 OPT_MAX_LAUNCH_SLICE = 11
 OPT_NO_PEAK_FILTER = 12
 OPT_NO_WAVE_CLIP_LONG = 13
+OPT_NO_CLIP_REUSE = 14
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 

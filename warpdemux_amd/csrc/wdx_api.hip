@@ -437,6 +437,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_EXACT_NO_PEAK_LIST: ctx->knobs.exact_no_list = value != 0; break;
         case WDX_OPT_NO_PEAK_FILTER: ctx->knobs.no_peak_filter = value != 0; break;
         case WDX_OPT_NO_WAVE_CLIP_LONG: ctx->knobs.no_wave_clip_long = value != 0; break;
+        case WDX_OPT_NO_CLIP_REUSE: ctx->knobs.no_clip_reuse = value != 0; break;
         case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);

@@ -33,6 +33,7 @@ struct Knobs {
     int fast_main_cap = 0;      // WDX_OPT_FAST_MAIN_CAP: 5120 / 6144 forces the main fast instantiation (0 = by batch)
     bool fast_exact_scores = false;  // WDX_OPT_FAST_EXACT_SCORES: fast fingerprint kernel without the approximate first attempt
     bool exact_no_list = false;      // WDX_OPT_EXACT_NO_PEAK_LIST: exact kernel's suppression / top-E in position space only
+    bool no_clip_reuse = false;      // WDX_OPT_NO_CLIP_REUSE: the exact kernel behind the chain recomputes its clip bounds
     bool no_wave_clip_long = false;  // WDX_OPT_NO_WAVE_CLIP_LONG: long windows' clip bounds by clip_bounds_block_kernel alone
     bool no_peak_filter = false;     // WDX_OPT_NO_PEAK_FILTER: fast kernels append every local maximum (no threshold filter)
     int64_t max_launch_slice = 0;    // WDX_OPT_MAX_LAUNCH_SLICE: upper bound of one launch slice of the fingerprint chain (0 = built-in)

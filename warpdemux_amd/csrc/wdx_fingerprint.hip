@@ -1170,11 +1170,23 @@ __device__ void fp_process_read(const FpArgs &A, const int64_t r, unsigned char 
     int any_nan = 0;          // (this thread saw a NaN sample / the bounds are NaN: only the refinement hand-over asks)
     float clip_lo = 0.f, clip_hi = 0.f;
     {
-        const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
-        const float mad =
-            block_nanmedian_f32<BLOCK>([&](int i) { return fabsf(sig[i] - med); }, n, hist, sh);
         float lo, hi;
-        clip_bounds(P, med, mad, lo, hi);
+        // behind the launch chain the bounds exist already (clip_bounds_kernel: the same float32 numbers; CLIP_OK also
+        // says that the window holds no NaN and lo <= hi) -- the two workgroup-wide selects are a quarter of this kernel
+        const ClipRec *crp = A.clip;
+        int cflag = CLIP_NONE;
+        if (crp) {
+            const ClipRec cr = crp[r];   // (block-uniform)
+            cflag = cr.flag;
+            lo = cr.lo;
+            hi = cr.hi;
+        }
+        if (cflag != CLIP_OK) {
+            const float med = block_nanmedian_f32<BLOCK>([&](int i) { return sig[i]; }, n, hist, sh);
+            const float mad =
+                block_nanmedian_f32<BLOCK>([&](int i) { return fabsf(sig[i] - med); }, n, hist, sh);
+            clip_bounds(P, med, mad, lo, hi);
+        }
         const bool bad = (lo != lo) || (hi != hi);
         __syncthreads();
         for (int i = tid; i < n; i += BLOCK) {
@@ -2027,6 +2039,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         }
         WDX_HIP_TRY(hipGetLastError());
         if (!chain) return WDX_SUCCESS;  // (ablation timing of the main kernel: the lists are left unprocessed)
+        // the exact kernels take the clip bounds of a read that has a CLIP_OK record (every read of the batch has a record by
+        // now: the main clip kernel writes one per read, the list forms fill in the longer windows) instead of redoing the
+        // two workgroup-wide medians
+        if (ext && !knobs.no_clip_reuse) A.clip = clip;
         if (rf) {
             // refinement branch: the exact kernel segments the adapters of the slow list's reads and leaves them, like the
             // fast kernels theirs, to the refinement kernels (reads it cannot hand over it refines in place); barcode

@@ -42,6 +42,7 @@ constexpr int kTailCap = 2048;        // barcode tails up to this many samples a
 constexpr int kRefineMaxQuery = 96;   // LDS budget of the subsequence DP (direction words + three fronts)
 constexpr int kRefineMaxSeries = 128;
 
+struct ClipRec;
 struct FpArgs {
     const float *sig;
     const int64_t *row_off;
@@ -69,6 +70,7 @@ struct FpArgs {
     int refine_record;   // exact kernel, refinement branch: 1 = leave a RefineRec for the refinement kernels where the read
                          // allows it (no NaN in the window, configured window width) instead of refining in place
     int peak_filter;     // fast kernels on approximate keys: 1 = drop peaks below kPeakTau at the append (WDX_OPT_NO_PEAK_FILTER)
+    const ClipRec *clip; // exact kernel behind the launch chain: the reads' clip records (CLIP_OK -> the two medians are not redone); nullable
 };
 
 // Clip bounds of one read, computed ahead of the fast kernels' launch chain by clip_bounds_kernel (one wave per read,
