@@ -1148,6 +1148,14 @@ def test_exact_kernel_behind_the_chain_takes_the_clip_records():
             fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
         assert np.array_equal(fb.status, status), (reuse_off, np.flatnonzero(fb.status != status))
         assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats), reuse_off
+        # ... and the exact kernel for the whole batch (WDX_OPT_EXACT_PATH; a width without a fast instantiation: 10), where
+        # large batches get their records from a clip launch of their own, with both signal normalisations
+        for kw2 in (dict(kw), dict(kw, running_stat_width=10), dict(kw, sig_norm="mean"), dict(kw, sig_norm="median")):
+            o2 = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw2))
+            with _chain(), _exact_path(), _option(_lib.OPT_NO_CLIP_REUSE, reuse_off):
+                ex = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw2))
+            assert np.array_equal(ex.status, o2[3]), (reuse_off, kw2)
+            assert _same(ex.fpt, o2[0]) and _same(ex.dwell, o2[1]) and _same(ex.stats, o2[2]), (reuse_off, kw2)
 
 
 def test_launch_chain_lists_longer_than_their_grids():

@@ -2088,6 +2088,15 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         }
         return WDX_SUCCESS;
     }
+    // The exact kernel for the whole batch (a window width or suppression reach without a fast instantiation, a signal
+    // normalisation, WDX_OPT_EXACT_PATH): large batches still get their clip bounds from the one-wave kernel first (windows
+    // up to 13 312 samples; 4.5 ms per million reads against the exact kernel's ~100 for its two workgroup-wide medians)
+    if (d_ws && !d_prof && !knobs.no_clip_reuse && n_reads >= (knobs.fast_chain_min > 0 ? knobs.fast_chain_min : 2048)) {
+        ClipRec *clip = reinterpret_cast<ClipRec *>(reinterpret_cast<unsigned char *>(d_ws) + 32);
+        const int ccap = max_len <= 4096 ? 4096 : (max_len <= 5120 ? 5120 : (max_len <= 6144 ? 6144 : (max_len <= 8192 ? 8192 : kClipWaveLongCap)));
+        if (int rc = launch_clip_bounds(A, clip, ccap, stream)) return rc;
+        A.clip = clip;
+    }
     if (int rc = small ? launch_fp_chunks<512, false>(A, lds, stream, n_launches)
                        : launch_fp_chunks<1024, false>(A, lds, stream, n_launches))
         return rc;
