@@ -209,7 +209,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     // inside [a, b]), the bin that holds rank k, and -- with at most 64 members -- their gather and ranking.  The first
     // level is straight-line code and only the rare later levels sit in a loop: inside a loop every expression of the
     // registers alone (the linear bins, 64 * NPL of them) is loop-invariant, gets hoisted and spills.
-    unsigned sk, sa, sb, sm;       // state of the select: rank, key range, number of members
+    unsigned sk, sa, sb;           // state of the select: rank, key range
     unsigned klo = 0, khi = 0;
     bool in_hi = false, done = false;
     float med = 0.0f, lin_scale = 0.0f;  // MAD
@@ -408,7 +408,6 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
         sa = wave_min_u32(mmn);
         sb = wave_max_u32(mmx);
         sk = kin;
-        sm = cnt;
         if (sa == sb) {  // every member equals sa
             klo = khi = sa;
             in_hi = kin + 1u < cnt;
@@ -417,7 +416,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
     };
     auto select = [&](auto mad_t, unsigned k, unsigned a, unsigned b, unsigned m, const bool want_hi) __attribute__((always_inline)) {
         constexpr bool MAD = decltype(mad_t)::value;
-        sk = k; sa = a; sb = b; sm = m;
+        sk = k; sa = a; sb = b;
         in_hi = false;
         done = false;
         if (a == b) {
