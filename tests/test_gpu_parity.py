@@ -1158,6 +1158,39 @@ def test_exact_kernel_behind_the_chain_takes_the_clip_records():
             assert _same(ex.fpt, o2[0]) and _same(ex.dwell, o2[1]) and _same(ex.stats, o2[2]), (reuse_off, kw2)
 
 
+@pytest.mark.parametrize("triple", [(110, 6, 12), (120, 9, 18)])
+def test_peak_lists_that_outgrow_the_last_list_kernel_go_to_the_exact_scores_launch(triple, golden_dir):
+    """A batch whose windows stay below 6 145 samples has no 8192-sample list kernel behind the 6144-sample one: a read
+    whose threshold-filtered peak list outgrows 512 entries there (clip-heavy reads with many level changes: ~740 local
+    maxima per 4.7 k samples, plateaus of equal scores where clipped samples slide in and out) is redone by the exact-scores
+    launch with its 1376 entries instead of the exact general kernel.  Same bits as the oracle either way."""
+    E, d, w = triple
+    rng = np.random.default_rng(97 + w)
+    n = 2304
+    consensus = np.load(os.path.join(golden_dir, "g8_refine.npz"))["consensus"]     # (84 levels of a tRNA adapter: wide spread)
+    rows = []
+    for i in range(n):
+        lv = np.concatenate([rng.normal(0, 1, int(rng.integers(2, 34))), consensus, rng.normal(0, 1, 30)]) * 12.0 + 85.0
+        dw = rng.integers(12, 60, lv.size)
+        x = np.repeat(lv, dw) + rng.normal(0, 1.5, int(dw.sum()))
+        rows.append(x[:6100].astype(np.float32))
+    stride = 6144
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    for i, r in enumerate(rows):
+        mb[i, :r.size] = r
+    a_s = np.zeros(n, dtype=np.int32)
+    a_e = np.array([r.size for r in rows], dtype=np.int32)
+    kw = dict(padding=0, num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25)
+    fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))      # n >= 2048: the launch chain
+    sub = np.arange(0, n, 3)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb[sub], a_s[sub], a_e[sub], orc.SegParams(**kw))
+    assert np.array_equal(fb.status[sub], status) and (status == 0).mean() > 0.5
+    assert _same(fb.fpt[sub], fpt) and _same(fb.dwell[sub], dwell) and _same(fb.stats[sub], stats)
+    with _exact_path():
+        sl = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+    assert np.array_equal(fb.status, sl.status) and _same(fb.fpt, sl.fpt) and _same(fb.dwell, sl.dwell)
+
+
 def test_launch_chain_lists_longer_than_their_grids():
     """The per-entry list kernels are launched with grids sized for the expected share of a batch (a quarter for
     windows beyond the main instantiation, 1/64 -- at least 1024 -- for exact-score retries); entries beyond the grid

@@ -1830,6 +1830,12 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool with_big1 = chain && capF >= 5120 && cap > 6144 && !with_stream;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
         A.peak_filter = knobs.no_peak_filter ? 0 : 1;   // (only the approximate-keys launches look at it)
+        static unsigned *d_reasons = nullptr;   // (diagnostic: one buffer per process, zeroed per call)
+        if (knobs.debug_occ) {
+            if (!d_reasons) WDX_HIP_TRY(hipMalloc(&d_reasons, 64));
+            WDX_HIP_TRY(hipMemsetAsync(d_reasons, 0, 64, stream));
+            A.dbg_reasons = d_reasons;
+        }
         FastArgs F{A, capF, capP, count, list, nullptr, nullptr, nullptr, nullptr, 0u, approx ? count + 3 : nullptr,
                    approx ? retry : nullptr, nullptr};
         if (with_big0) {
@@ -2074,6 +2080,15 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                             "streaming kernel, %u redone with exact scores, %u on the exact general kernel\n", (long long)n_reads,
                     c[1], c[2], with_stream ? "redone by the streaming kernel on exact scores" : "to the 8192-sample list kernel",
                     c[4], c[3], c[0]);
+            {
+                unsigned h[16];
+                WDX_HIP_TRY(hipMemcpy(h, d_reasons, 64, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[wdx] handed to the exact kernel by the fast kernels, by reason (0 parameter gate / window, 1 NaN or negative, "
+                                "2 sums not provably exact, 3 plateau or peak-list capacity, 4 neighbourhood, 5 kept-list capacity, 6 tie at the "
+                                "top-E cut, 7 doubt without a retry list, 8 fewer peaks than events with accept_less_cpts):");
+                for (int i = 0; i < 10; ++i) fprintf(stderr, " %u", h[i]);
+                fprintf(stderr, "\n");
+            }
             if (rf)
                 fprintf(stderr, "[wdx] refinement: %u reads back from the tail kernel to the exact kernel (%u for a run of equal scores across a "
                                 "tile's end, %u beyond the peak list)\n", c[5], c[6], c[7]);

@@ -70,6 +70,7 @@ struct FpArgs {
     int refine_record;   // exact kernel, refinement branch: 1 = leave a RefineRec for the refinement kernels where the read
                          // allows it (no NaN in the window, configured window width) instead of refining in place
     int peak_filter;     // fast kernels on approximate keys: 1 = drop peaks below kPeakTau at the append (WDX_OPT_NO_PEAK_FILTER)
+    unsigned *dbg_reasons;  // WDX_OPT_DEBUG_OCCUPANCY: 16 counters, why the fast kernels handed reads to the exact kernel (else null)
     const ClipRec *clip; // exact kernel behind the launch chain: the reads' clip records (CLIP_OK -> the two medians are not redone); nullable
 };
 
