@@ -1191,6 +1191,44 @@ def test_peak_lists_that_outgrow_the_last_list_kernel_go_to_the_exact_scores_lau
     assert np.array_equal(fb.status, sl.status) and _same(fb.fpt, sl.fpt) and _same(fb.dwell, sl.dwell)
 
 
+@pytest.mark.parametrize("triple", [(110, 6, 12), (120, 9, 18), (110, 15, 30), (110, 3, 6), (110, 12, 24), (110, 17, 36)])
+def test_long_plateaus_of_equal_scores(triple):
+    """One deviating sample inside a long stretch of equal samples (what the outlier clip leaves of a stalled read) gives
+    2 W exactly equal scores between zeros -- scipy's plateau rule puts ONE peak at their midpoint.  Integer-valued samples
+    and a deviation that is a multiple of W make every operation exact, so the ties are exact in the reference as well.
+    The fast kernels follow such a plateau lane by lane to the end of a wave's scores (registers hold the next two lanes');
+    plateaus across a wave's or a tile's end, and at the very end of the score curve, take the exact kernel.  Same
+    change-points as the oracle in every case."""
+    E, d, w = triple
+    rng = np.random.default_rng(1000 * w + d)
+    n, stride = 96, 9000
+    mb = np.full((n, stride), np.nan, dtype=np.float32)
+    a_e = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        ln = int(rng.integers(4200, 8800))
+        dw = int(rng.integers(14, 40))
+        x = np.round(np.repeat(rng.normal(80, 15, ln // dw + 1), dw)[:ln] + rng.normal(0, 2, ln))
+        run = 4 * w + int(rng.integers(4, 40))
+        starts = list(rng.integers(100, ln - run - 100, 10)) + [ln - run]          # (the last one: up to the window's end)
+        for s0 in starts:
+            x[s0:s0 + run] = 400.0
+            x[s0 + int(rng.integers(2 * w, run - 2 * w + 1))] = 400.0 - 360.0 * int(rng.integers(1, 2))   # 360 = lcm of the widths
+        mb[i, :ln] = x
+        a_e[i] = ln
+    a_s = np.zeros(n, dtype=np.int32)
+    kw = dict(padding=0, num_events=E, min_obs_per_base=d, running_stat_width=w, barcode_num_events=25, outlier_thresh=1.0e6)
+    fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(**kw))
+    assert (status == 0).sum() > 0.6 * n
+    for chain in (False, True):
+        if chain:
+            with _chain():
+                fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        else:
+            fb = sig_proc.fingerprint_batch(mb, a_s, a_e, sig_proc.SegParams(**kw))
+        assert np.array_equal(fb.status, status), (chain, np.flatnonzero(fb.status != status))
+        assert _same(fb.fpt, fpt) and _same(fb.dwell, dwell) and _same(fb.stats, stats), chain
+
+
 def test_launch_chain_lists_longer_than_their_grids():
     """The per-entry list kernels are launched with grids sized for the expected share of a batch (a quarter for
     windows beyond the main instantiation, 1/64 -- at least 1024 -- for exact-score retries); entries beyond the grid
