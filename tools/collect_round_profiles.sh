@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*: default bench line, bench under rocprofv3 --stats (+ kernel stats CSV), HBM traffic
 #    (FETCH_SIZE / WRITE_SIZE passes), SQ/LDS counters per kernel, per-phase counters and phase ablation of the
 #    fast fingerprint kernel.  Copy what should be judged into profiles/.
-TAG=${1:-r05g}
+TAG=${1:-r05h}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
