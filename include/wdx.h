@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define WDX_ABI_VERSION 3
+#define WDX_ABI_VERSION 4
 
 /* ---- call status ------------------------------------------------------------------------- */
 #define WDX_SUCCESS 0
@@ -259,6 +259,46 @@ int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_rea
                      const int32_t *a_start, const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
                      int64_t n_refs, int32_t want_fpt, int32_t want_dist);
 int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t *call, int32_t *status);
+/* The same pipeline with everything the reference's worker needs from a minibatch (file_proc.py:380-454: the
+ * ReadResults -- fingerprint, dwell times, six statistics, sig_proc.py:562-605 -- AND model.predict of the stacked
+ * fingerprints, models/dtw_svm.py:54-98) produced by ONE pass over the rows:
+ *   wdx_demux_submit_ex(ctx, slot, in, p, n_refs, want)   `want` = WDX_WANT_* bits; status and call always come back.
+ *                                                         in->row_off != NULL: the rows are PACKED -- row r holds only the
+ *                                                         samples the kernels read, sig[row_off[r] .. + row_len[r]), and
+ *                                                         a_start / a_end are relative to it (what a worker that copies
+ *                                                         [a_start - padding, a_end + padding) of each read hands over:
+ *                                                         half the bytes of the NaN-padded rows); row_off[r] % 4 == 0.
+ *                                                         WDX_WANT_SVM needs wdx_svm_set_model (a model trained on the
+ *                                                         resident references); reads whose fingerprint failed get
+ *                                                         pred -1 and NaN prob / conf, like wdx_demux_svm_dev.
+ *   wdx_demux_wait_ex(ctx, slot, out)                     out->X may be NULL for anything; an output that was not asked
+ *                                                         for at submit is WDX_ERR_INVALID and leaves the slot busy.
+ * Bit-identical to wdx_fingerprint_batch / wdx_demux_batch / wdx_dtw_svm_predict on the same rows. */
+#define WDX_WANT_FPT 0x01u   /* fpt   (n, K) float64                                      */
+#define WDX_WANT_DIST 0x02u  /* dist  (n, n_refs) float32                                 */
+#define WDX_WANT_DWELL 0x04u /* dwell (n, K) int64                                        */
+#define WDX_WANT_STATS 0x08u /* stats (n, 6) float64 (order: wdx_fingerprint_batch)       */
+#define WDX_WANT_SVM 0x10u   /* prob (n, k) float64, pred int32[n], conf float64[n]       */
+typedef struct wdx_minibatch_in {
+    const float *sig;          /* (n_reads, stride) rows, or the packed rows when row_off != NULL             */
+    int64_t n_reads, stride;   /* stride is ignored for packed rows                                          */
+    const int64_t *row_off;    /* packed: int64[n_reads + 1], multiples of 4; NULL = minibatch layout        */
+    const int32_t *row_len;    /* packed: samples of row r (<= row_off[r+1] - row_off[r])                    */
+    const int32_t *a_start, *a_end;
+    const uint8_t *ok;         /* nullable                                                                    */
+} wdx_minibatch_in;
+typedef struct wdx_minibatch_out {
+    int32_t *status, *call;
+    float *dist;
+    double *fpt;
+    int64_t *dwell;
+    double *stats, *prob;
+    int32_t *pred;
+    double *conf;
+} wdx_minibatch_out;
+int wdx_demux_submit_ex(wdx_ctx *ctx, int32_t slot, const wdx_minibatch_in *in, const wdx_seg_params *p, int64_t n_refs,
+                        uint32_t want);
+int wdx_demux_wait_ex(wdx_ctx *ctx, int32_t slot, const wdx_minibatch_out *out);
 /* Page-locked host memory for minibatch buffers the caller fills (what file_proc.py:244-260 allocates with
  * np.full): the GPU reads it directly.  Needs no context; free with wdx_host_free. */
 int wdx_host_alloc(size_t bytes, void **out);
@@ -278,25 +318,71 @@ int wdx_host_unregister(void *p);
  *      have that problem.  The ring lives in shared memory the caller maps in every process (parent: create + init BEFORE
  *      the fork; Python: warpdemux_amd.feeder.Feeder):
  *        wdx_feeder_ring_bytes / _init   size and lay out the ring: n_slots (<= WDX_FEEDER_MAX_RING_SLOTS) minibatches of at
- *                                        most max_reads x max_stride float32 samples, distances to n_refs references.
- *                                        (A worker holds its ring slot while it copies 40 MB in and the results out; the
- *                                        feeder keeps at most WDX_MAX_SLOTS of the READY ones in flight on the device.)
- *        wdx_feeder_serve(ctx, ring, p)  the GPU-facing process: page-locks the ring and serves it until wdx_feeder_stop --
- *                                        every READY slot goes through wdx_demux_submit, the oldest in flight through
- *                                        wdx_demux_wait; the context's resident references (wdx_set_refs) classify
- *        wdx_feeder_demux(ring, ...)     a worker: wdx_demux_batch's arguments and outputs (bit-identical results), but
- *                                        no context and NO HIP call -- the minibatch is copied into a free slot, the
- *                                        worker sleeps on the slot (futex) until the results are there.  n_reads x stride
- *                                        must fit a slot; WDX_ERR_NO_DEVICE when the feeder has stopped or died
- *        wdx_feeder_stop(ring)           ends wdx_feeder_serve (it first drains what is in flight) */
+ *                                        most max_reads x max_stride float32 samples, distances to n_refs references,
+ *                                        n_events > 0: room for fingerprints / dwell times / statistics (K = n_events =
+ *                                        p->barcode_num_events), n_classes > 0: room for the DTW_SVM outputs.  `p` = the
+ *                                        parameters every minibatch is fingerprinted with (kept in the ring: the workers
+ *                                        pack their rows with its `padding`).
+ *                                        (A worker holds its ring slot while it copies its windows in and the results out;
+ *                                        the feeder keeps at most WDX_MAX_SLOTS of the READY ones in flight on the device.)
+ *        wdx_feeder_serve(ctx, ring)     the GPU-facing process: page-locks the ring and serves it until wdx_feeder_stop --
+ *                                        every READY slot goes through wdx_demux_submit_ex, the oldest in flight through
+ *                                        wdx_demux_wait_ex; the context's resident references (wdx_set_refs) classify, its
+ *                                        resident model (wdx_svm_set_model) serves WDX_WANT_SVM and wdx_feeder_predict
+ *        wdx_feeder_run(ring, job)       a worker: one minibatch, `job->want` = WDX_WANT_* bits -- what the reference's
+ *                                        worker needs from it (file_proc.py:380-454): status + fpt + dwell + stats (the
+ *                                        ReadResults, = wdx_fingerprint_batch), call + dist (= wdx_demux_batch), prob +
+ *                                        pred + conf (= model.predict of the stacked fingerprints, models/dtw_svm.py:54-98;
+ *                                        failed reads: pred -1, NaN) -- from ONE pass, bit-identical to those calls.  No
+ *                                        context and NO HIP call: only samples [a_start - padding, a_end + padding) of each
+ *                                        row are copied into a free slot (packed rows), the worker sleeps on the slot
+ *                                        (futex) until the results are there.  WDX_ERR_NO_DEVICE when the feeder has
+ *                                        stopped or died (a dead feeder is noticed even while it is an unreaped zombie)
+ *        wdx_feeder_demux(ring, ...)     wdx_demux_batch's arguments through wdx_feeder_run (status, call, dist)
+ *        wdx_feeder_predict(ring, X, ..) DTW_SVM.predict on (n, n_events) float64 fingerprints the worker holds
+ *        wdx_feeder_stop(ring)           ends wdx_feeder_serve: minibatches in flight are finished and handed over, READY
+ *                                        ones that were never submitted are answered WDX_ERR_NO_DEVICE, new claims are
+ *                                        refused
+ *      A worker that dies while it holds a slot does not leak it: the slot's owner pid is part of its state word, and the
+ *      serve loop (and any claimant that finds the ring full) gives slots of dead owners back to the ring. */
 #define WDX_FEEDER_MAX_RING_SLOTS 32
-size_t wdx_feeder_ring_bytes(int32_t n_slots, int64_t max_reads, int64_t max_stride, int64_t n_refs);
-int wdx_feeder_ring_init(void *mem, size_t bytes, int32_t n_slots, int64_t max_reads, int64_t max_stride, int64_t n_refs);
-int wdx_feeder_serve(wdx_ctx *ctx, void *ring, const wdx_seg_params *p);
+typedef struct wdx_feeder_geometry {
+    int32_t n_slots;
+    int32_t n_events;    /* K of fpt / dwell (0: no room for WDX_WANT_FPT / _DWELL / _STATS)      */
+    int32_t n_classes;   /* k of prob (0: no room for WDX_WANT_SVM / wdx_feeder_predict), <= 16  */
+    int32_t pad_;
+    int64_t max_reads, max_stride, n_refs;
+} wdx_feeder_geometry;
+typedef struct wdx_feeder_job {
+    const float *sig;          /* (n_reads, stride) float32 rows, NaN tail (file_proc.py:244-260)               */
+    int64_t n_reads, stride;
+    const int32_t *a_start, *a_end;
+    const uint8_t *ok;         /* nullable                                                                       */
+    uint32_t want, pad_;       /* WDX_WANT_* bits                                                                */
+    /* outputs: caller-owned host arrays; status is required, call nullable, the others where their bit is set   */
+    int32_t *status, *call;
+    float *dist;               /* (n_reads, n_refs)                                                              */
+    double *fpt;               /* (n_reads, n_events)                                                            */
+    int64_t *dwell;            /* (n_reads, n_events)                                                            */
+    double *stats;             /* (n_reads, 6)                                                                   */
+    double *prob;              /* (n_reads, n_classes)                                                           */
+    int32_t *pred;
+    double *conf;
+} wdx_feeder_job;
+size_t wdx_feeder_ring_bytes(const wdx_feeder_geometry *g);
+int wdx_feeder_ring_init(void *mem, size_t bytes, const wdx_feeder_geometry *g, const wdx_seg_params *p);
+int wdx_feeder_serve(wdx_ctx *ctx, void *ring);
+int wdx_feeder_run(void *ring, const wdx_feeder_job *job);
 int wdx_feeder_demux(void *ring, const float *sig, int64_t n_reads, int64_t stride, const int32_t *a_start,
                      const int32_t *a_end, const uint8_t *ok, int64_t n_refs, float *dist, int32_t *call, int32_t *status);
+int wdx_feeder_predict(void *ring, const double *X, int64_t n, double *prob, int32_t *pred, double *conf);
 int wdx_feeder_stop(void *ring);
 int wdx_feeder_served(void *ring, int64_t *minibatches);   /* minibatches handed back so far */
+/* served minibatches, slots taken back from dead workers, slots FREE right now (outputs nullable) */
+int wdx_feeder_stats(void *ring, int64_t *served, int64_t *reclaimed, int32_t *free_slots);
+/* Test hooks (no GPU): 1 = claim a slot for the calling process and leave it FILLING (returns its index), 2 = pose as the
+ * serving feeder without serving.  Never on the product path. */
+int wdx_feeder_selftest(void *ring, int32_t what);
 int wdx_feeder_alive(void *ring);   /* 1 while a feeder process serves the ring, 0 once it has stopped or died (< 0: error) */
 
 /* Live path (BASELINE config 5; N4): every read of one 100 ms chunk round in one call -- the batched form of

@@ -264,7 +264,29 @@ def test_feeder_serves_forked_workers_and_reports_its_own_death():
     assert len(rec["pids"]) >= 2 and rec["parent"] not in rec["pids"]
     assert all(all(w) for w in rec["ok"]), rec
     assert all(e == [True, True] for e in rec["errs"]), rec
-    assert rec["served"] == 16 and rec["after_death"].startswith("told"), rec
+    assert rec["served"] == 32 and rec["after_death"].startswith("told"), rec
+    # (killed and not reaped when the worker called: kill(pid, 0) would still have called it alive)
+    assert rec["feeder_state_when_the_worker_was_told"] == "Z", rec
+    # a worker SIGKILLed with a slot in its hands: the ring has all its slots again
+    assert rec["reclaim"]["reclaimed"] == 1 and rec["reclaim"]["free_slots"] == rec["reclaim"]["n_slots"], rec
+
+
+def test_feeder_returns_the_reference_workers_whole_minibatch_on_a_real_model():
+    """VERDICT r5 missing 2: the reference worker (file_proc.py:380-454) needs the ReadResults (fingerprint, dwell, six
+    statistics) AND model.predict of the stacked fingerprints.  feeder.detect_and_predict / fingerprint_batch / predict with
+    the REAL WDX10_rna004_v1_0 model (fixture g6b): predict against the reference's own output, the fingerprints against
+    the oracle bit for bit, the end-to-end probabilities against the oracle (1e-5) and against this package's in-process
+    DTW_SVM.predict (bit for bit), ReadResult records and the predictions DataFrame."""
+    rc, so, se = _run_bounded([sys.executable, os.path.join(ROOT, "tests", "helpers", "feeder_model_check.py")])
+    assert rc == 0, se[-2000:]
+    rec = json.loads(so.strip().splitlines()[-1])
+    assert len(rec["pids"]) >= 2 and rec["parent"] not in rec["pids"]
+    for w in rec["workers"]:
+        assert w["predict_max_abs_prob_err_vs_reference"] <= 1e-5 and w["predict_labels"] and w["predict_df"], w
+        assert w["fingerprints"] and w["records"], w
+        assert w["rows"][0] == w["rows"][1] == w["rows"][2] and w["rows"][0] >= 80, w
+        assert w["e2e_max_abs_prob_err_vs_oracle"] <= 1e-5, w
+    assert all(rec["feeder_equals_in_process_predict"]), rec
 
 
 def test_context_leaves_the_callers_device_alone_and_rejects_use_after_fork_pid():

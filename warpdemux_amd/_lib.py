@@ -36,7 +36,7 @@ OPT_NO_PEAK_FILTER = 12
 OPT_NO_WAVE_CLIP_LONG = 13
 OPT_NO_CLIP_REUSE = 14
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 NORM_CODES = {"none": 0, "mean": 1, "median": 2}
 
@@ -45,12 +45,13 @@ EXPORTS = [
     "wdx_abi_version", "wdx_last_error", "wdx_device_count", "wdx_ctx_create", "wdx_ctx_destroy",
     "wdx_ctx_synchronize", "wdx_ctx_stream", "wdx_ctx_set_option", "wdx_comm_available", "wdx_comm_info", "wdx_comm_unique_id", "wdx_comm_init",
     "wdx_comm_destroy", "wdx_reduce_counts", "wdx_reduce_counts_host", "wdx_dtw_matrix", "wdx_set_refs", "wdx_refs_generation", "wdx_dtw_matrix_dev",
-    "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_refine_dev", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait",
+    "wdx_fingerprint_batch", "wdx_fingerprint_refine_batch", "wdx_fingerprint_refine_dev", "wdx_fingerprint_dev", "wdx_demux_batch", "wdx_demux_submit", "wdx_demux_wait", "wdx_demux_submit_ex", "wdx_demux_wait_ex",
     "wdx_host_alloc", "wdx_host_alloc_on", "wdx_host_free", "wdx_host_register", "wdx_host_unregister", "wdx_live_tick", "wdx_svm_set_model",
     "wdx_svm_predict_dev", "wdx_dtw_svm_predict", "wdx_demux_svm_dev", "wdx_demux_workspace_bytes", "wdx_demux_dev",
     "wdx_kernel_timing", "wdx_kernel_time", "wdx_kernel_time_reset", "wdx_synth_lengths_dev",
     "wdx_synth_fill_dev", "wdx_fingerprint_profile_dev", "wdx_calib_read_dev", "wdx_selftest_score_dev", "wdx_selftest_clip_dev",
-    "wdx_feeder_ring_bytes", "wdx_feeder_ring_init", "wdx_feeder_serve", "wdx_feeder_demux", "wdx_feeder_stop", "wdx_feeder_served", "wdx_feeder_alive",
+    "wdx_feeder_ring_bytes", "wdx_feeder_ring_init", "wdx_feeder_serve", "wdx_feeder_run", "wdx_feeder_demux", "wdx_feeder_predict", "wdx_feeder_stop",
+    "wdx_feeder_served", "wdx_feeder_stats", "wdx_feeder_alive", "wdx_feeder_selftest",
 ]
 
 
@@ -109,6 +110,52 @@ class SvmModelC(C.Structure):
     ]
 
 
+WANT_FPT, WANT_DIST, WANT_DWELL, WANT_STATS, WANT_SVM = 0x01, 0x02, 0x04, 0x08, 0x10   # WDX_WANT_*
+
+
+class MinibatchInC(C.Structure):
+    """wdx_minibatch_in (include/wdx.h)"""
+
+    _fields_ = [
+        ("sig", C.c_void_p), ("n_reads", C.c_int64), ("stride", C.c_int64), ("row_off", C.c_void_p), ("row_len", C.c_void_p),
+        ("a_start", C.c_void_p), ("a_end", C.c_void_p), ("ok", C.c_void_p),
+    ]
+
+
+class MinibatchOutC(C.Structure):
+    """wdx_minibatch_out (include/wdx.h)"""
+
+    _fields_ = [
+        ("status", C.c_void_p), ("call", C.c_void_p), ("dist", C.c_void_p), ("fpt", C.c_void_p), ("dwell", C.c_void_p),
+        ("stats", C.c_void_p), ("prob", C.c_void_p), ("pred", C.c_void_p), ("conf", C.c_void_p),
+    ]
+
+
+class FeederGeometryC(C.Structure):
+    """wdx_feeder_geometry (include/wdx.h)"""
+
+    _fields_ = [
+        ("n_slots", C.c_int32), ("n_events", C.c_int32), ("n_classes", C.c_int32), ("pad_", C.c_int32),
+        ("max_reads", C.c_int64), ("max_stride", C.c_int64), ("n_refs", C.c_int64),
+    ]
+
+
+class FeederJobC(C.Structure):
+    """wdx_feeder_job (include/wdx.h)"""
+
+    _fields_ = [
+        ("sig", C.c_void_p), ("n_reads", C.c_int64), ("stride", C.c_int64), ("a_start", C.c_void_p), ("a_end", C.c_void_p),
+        ("ok", C.c_void_p), ("want", C.c_uint32), ("pad_", C.c_uint32),
+        ("status", C.c_void_p), ("call", C.c_void_p), ("dist", C.c_void_p), ("fpt", C.c_void_p), ("dwell", C.c_void_p),
+        ("stats", C.c_void_p), ("prob", C.c_void_p), ("pred", C.c_void_p), ("conf", C.c_void_p),
+    ]
+
+
+def addr(a):
+    """Address of a NumPy array as an int for a c_void_p FIELD of a ctypes structure (None -> NULL)."""
+    return None if a is None else a.ctypes.data
+
+
 class WdxError(RuntimeError):
     pass
 
@@ -163,6 +210,12 @@ def load():
         P = C.POINTER
         L.wdx_abi_version.restype = C.c_int
         L.wdx_abi_version.argtypes = []
+        # (checked before any other symbol is bound: an older library then fails with this message, not with an
+        # AttributeError on the first export it lacks)
+        have = L.wdx_abi_version()
+        if have != ABI_VERSION:
+            raise WdxError(f"{LIB_PATH}: ABI version {have}, this package binds version {ABI_VERSION} -- rebuild it "
+                           "(make -C warpdemux_amd/csrc)")
         L.wdx_last_error.restype = C.c_char_p
         L.wdx_last_error.argtypes = []
         L.wdx_device_count.restype = C.c_int
@@ -255,22 +308,32 @@ def load():
         L.wdx_synth_lengths_dev.argtypes = [vp, u64, i64, i64, i32, vp, vp, vp]
         L.wdx_synth_fill_dev.restype = C.c_int
         L.wdx_synth_fill_dev.argtypes = [vp, u64, i64, i64, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.wdx_demux_submit_ex.restype = C.c_int
+        L.wdx_demux_submit_ex.argtypes = [vp, i32, P(MinibatchInC), P(SegParamsC), i64, C.c_uint32]
+        L.wdx_demux_wait_ex.restype = C.c_int
+        L.wdx_demux_wait_ex.argtypes = [vp, i32, P(MinibatchOutC)]
         L.wdx_feeder_ring_bytes.restype = C.c_size_t
-        L.wdx_feeder_ring_bytes.argtypes = [i32, i64, i64, i64]
+        L.wdx_feeder_ring_bytes.argtypes = [P(FeederGeometryC)]
         L.wdx_feeder_ring_init.restype = C.c_int
-        L.wdx_feeder_ring_init.argtypes = [vp, C.c_size_t, i32, i64, i64, i64]
+        L.wdx_feeder_ring_init.argtypes = [vp, C.c_size_t, P(FeederGeometryC), P(SegParamsC)]
         L.wdx_feeder_serve.restype = C.c_int
-        L.wdx_feeder_serve.argtypes = [vp, vp, P(SegParamsC)]
+        L.wdx_feeder_serve.argtypes = [vp, vp]
+        L.wdx_feeder_run.restype = C.c_int
+        L.wdx_feeder_run.argtypes = [vp, P(FeederJobC)]
         L.wdx_feeder_demux.restype = C.c_int
         L.wdx_feeder_demux.argtypes = [vp, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
+        L.wdx_feeder_predict.restype = C.c_int
+        L.wdx_feeder_predict.argtypes = [vp, vp, i64, vp, vp, vp]
         L.wdx_feeder_stop.restype = C.c_int
         L.wdx_feeder_stop.argtypes = [vp]
         L.wdx_feeder_served.restype = C.c_int
         L.wdx_feeder_served.argtypes = [vp, P(i64)]
+        L.wdx_feeder_stats.restype = C.c_int
+        L.wdx_feeder_stats.argtypes = [vp, P(i64), P(i64), P(i32)]
         L.wdx_feeder_alive.restype = C.c_int
         L.wdx_feeder_alive.argtypes = [vp]
-        if L.wdx_abi_version() != ABI_VERSION:
-            raise WdxError("libwdx_hip.so ABI version mismatch")
+        L.wdx_feeder_selftest.restype = C.c_int
+        L.wdx_feeder_selftest.argtypes = [vp, i32]
         _lib = L
         return L
 

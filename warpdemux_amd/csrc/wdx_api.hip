@@ -403,7 +403,8 @@ void wdx_ctx_destroy(wdx_ctx *ctx) {
     comm_destroy(ctx);
     for (Buffer *b : {&ctx->refs_pad, &ctx->refs_T, &ctx->refs_nan, &ctx->in0, &ctx->in1, &ctx->in2,
                       &ctx->in3, &ctx->out0, &ctx->out1, &ctx->out2, &ctx->out3, &ctx->tmp0,
-                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws, &ctx->pk_idx, &ctx->svm_fused, &ctx->svm_refs})
+                      &ctx->tmp1, &ctx->tmp2, &ctx->scratch, &ctx->fp_ws, &ctx->svm_buf, &ctx->ref_buf, &ctx->fp_big, &ctx->ref_ws, &ctx->pk_idx, &ctx->svm_fused, &ctx->svm_refs,
+                      &ctx->mb_dwell, &ctx->mb_stats, &ctx->mb_prob, &ctx->mb_pred, &ctx->mb_conf})
         b->release();
     ctx->pin_in.release();
     ctx->pin_out.release();
@@ -848,31 +849,47 @@ int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
 }
 
 // Body of the fused host-buffer call.  `B` owns the stream and every workspace that is touched (the context itself
-// for wdx_demux_batch; one of its two pipeline slots for wdx_demux_submit), `R` is the resident reference set
-// (read-only device memory of the parent context).  Everything is ENQUEUED on B->stream -- copies in, the kernel
-// chain, copies out to the four host destinations (caller arrays or the slot's page-locked block); the caller
-// synchronises.  Only the columns that hold adapter windows travel (the rows are NaN-padded to sig_preload_size,
-// file_proc.py:244-260; the kernels never read outside [start, stop)).
-static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, int64_t n_reads, int64_t stride,
-                               const int32_t *a_start, const int32_t *a_end, const uint8_t *ok,
-                               const wdx_seg_params *p, double *h_fpt, float *h_dist, int32_t *h_call,
-                               int32_t *h_status) {
+// for wdx_demux_batch; one of its pipeline slots for wdx_demux_submit[_ex]), `R` is the resident reference set
+// (read-only device memory of the parent context), `svm` the parent's resident model when the SVM tail is asked for.
+// Everything is ENQUEUED on B->stream -- copies in, the kernel chain, copies out to the host destinations (caller arrays
+// or the slot's page-locked block); the caller synchronises.  Only the columns that hold adapter windows travel (the
+// rows are NaN-padded to sig_preload_size, file_proc.py:244-260; the kernels never read outside [start, stop)).
+struct MbHostOut {  // host destinations of one minibatch; null = not wanted (status always)
+    int32_t *status = nullptr, *call = nullptr;
+    float *dist = nullptr;
+    double *fpt = nullptr;
+    int64_t *dwell = nullptr;
+    double *stats = nullptr, *prob = nullptr;
+    int32_t *pred = nullptr;
+    double *conf = nullptr;
+};
+
+static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const wdx_minibatch_in &in, const wdx_seg_params *p,
+                               const MbHostOut &H, const SvmDev *svm) {
     int rc = WDX_SUCCESS;
     hipStream_t s = B->stream;
+    const float *sig = in.sig;
+    const int64_t n_reads = in.n_reads, stride = in.stride;
+    const int32_t *a_start = in.a_start, *a_end = in.a_end;
+    const uint8_t *ok = in.ok;
     const int64_t K = p->barcode_num_events;
+    const bool packed_in = in.row_off != nullptr;
     int64_t max_len = 0, col0 = stride, col1 = 0;  // columns [col0, col1) hold every adapter window of the batch
+    int64_t win_total = 0;
     for (int64_t r = 0; r < n_reads; ++r) {
         if (ok && !ok[r]) continue;
+        const int64_t rl = packed_in ? (int64_t)in.row_len[r] : stride;
         int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
         if (st < 0) st = 0;
-        if (en > stride) en = stride;
+        if (en > rl) en = rl;
         if (en - st > max_len) max_len = en - st;
         if (en > st) {
+            win_total += en - st;
             if (st < col0) col0 = st;
             if (en > col1) col1 = en;
         }
     }
-    const size_t sb = (size_t)(n_reads * stride) * sizeof(float);
+    const size_t sb = (size_t)(packed_in ? in.row_off[n_reads] : n_reads * stride) * sizeof(float);
     const size_t db = (size_t)(n_reads * (R.nY > 0 ? R.nY : 1)) * sizeof(float);
     if ((rc = B->in0.ensure(sb ? sb : 4))) return rc;
     if ((rc = B->in1.ensure((size_t)n_reads * 4))) return rc;
@@ -882,34 +899,54 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
     if ((rc = B->out1.ensure(db))) return rc;
     if ((rc = B->out2.ensure((size_t)n_reads * 4))) return rc;
     if ((rc = B->out3.ensure((size_t)n_reads * 4))) return rc;
+    if (H.dwell && (rc = B->mb_dwell.ensure((size_t)(n_reads * K) * 8))) return rc;
+    if (H.stats && (rc = B->mb_stats.ensure((size_t)n_reads * 48))) return rc;
+    if (svm) {
+        if ((rc = B->mb_prob.ensure((size_t)n_reads * svm->k * 8))) return rc;
+        if ((rc = B->mb_pred.ensure((size_t)n_reads * 4))) return rc;
+        if ((rc = B->mb_conf.ensure((size_t)n_reads * 8))) return rc;
+    }
     if ((rc = B->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     if ((rc = B->fp_big.ensure((size_t)fingerprint_big_bytes(max_len)))) return rc;
+    int64_t *d_dwell = H.dwell ? (int64_t *)B->mb_dwell.p : nullptr;
+    double *d_stats = H.stats ? (double *)B->mb_stats.p : nullptr;
     // (Letting the FINGERPRINT kernel read a page-locked minibatch in place over the bus was measured and lost: 1.80 M
     // reads/s against 2.46 M with a DMA copy, which runs at 49 GB/s.)
-    // Two ways in.  (i) The 2-D DMA copy of the column range that holds every adapter window of the batch -- all a
+    // Three ways in.  (i) The 2-D DMA copy of the column range that holds every adapter window of the batch -- all a
     // pageable array allows, and the best there is when every read's adapter starts at the same sample.  (ii) Rows that
     // carry whole reads have their adapters at different places (sig_proc.py:382-391: adapter_start varies per read) and
     // the column union is most of the row: when the minibatch is page-locked (wdx_host_alloc) and the windows are less
     // than 0.85 of the union, a copy kernel reads ONLY the windows over the bus, back to back into a packed device
     // buffer (pack_windows_kernel: pure copy, every load in flight), and the kernels run on the packed layout -- row r =
-    // the original row's samples [st_r, en_r), adapter bounds shifted by st_r: the same window, bit for bit.
-    int64_t win_total = 0;
-    for (int64_t r = 0; r < n_reads; ++r) {
-        if (ok && !ok[r]) continue;
-        int64_t st = (int64_t)a_start[r] - p->padding, en = (int64_t)a_end[r] + p->padding;
-        if (st < 0) st = 0;
-        if (en > stride) en = stride;
-        if (en > st) win_total += en - st;
-    }
+    // the original row's samples [st_r, en_r), adapter bounds shifted by st_r: the same window, bit for bit.  (iii) Rows the
+    // CALLER packed (wdx_minibatch_in.row_off; the feeder's workers): one flat copy of exactly the windows.
     const float *sig_dev = nullptr;  // the minibatch as the device sees it, when it is page-locked
-    if (col1 > col0 && (double)win_total < 0.85 * (double)((col1 - col0) * n_reads)) {
+    if (!packed_in && col1 > col0 && (double)win_total < 0.85 * (double)((col1 - col0) * n_reads)) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, sig) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
             sig_dev = (const float *)at.devicePointer;
         else
             (void)hipGetLastError();
     }
-    if (sig_dev) {
+    if (packed_in) {
+        // device images: off int64[n+1] | len int32[n] | a_start int32[n] | a_end int32[n], straight from the caller's arrays
+        const size_t ib = (size_t)(n_reads + 1) * 8 + (size_t)n_reads * 12;
+        if ((rc = B->pk_idx.ensure(ib))) return rc;
+        int64_t *d_off = (int64_t *)B->pk_idx.p;
+        int32_t *d_len = (int32_t *)(d_off + n_reads + 1), *d_as = d_len + n_reads, *d_ae = d_as + n_reads;
+        if (sb) WDX_HIP_TRY(hipMemcpyAsync(B->in0.p, sig, sb, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(d_off, in.row_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(d_len, in.row_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(d_as, a_start, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        WDX_HIP_TRY(hipMemcpyAsync(d_ae, a_end, (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+        if (ok) WDX_HIP_TRY(hipMemcpyAsync(B->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
+        Timed t(B, WDX_K_FINGERPRINT, s);
+        if ((rc = launch_fingerprint((const float *)B->in0.p, d_off, d_len, 0, max_len, n_reads, d_as, d_ae,
+                                     ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p, d_dwell, d_stats,
+                                     (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
+                                     &t.main, (double *)B->fp_big.p)))
+            return rc;
+    } else if (sig_dev) {
         // host images (page-locked, owned by the slot until its copy has run): off int64[n+1] | st int32[n] | len
         // int32[n] | a_start' int32[n] | a_end' int32[n]
         const size_t ib = (size_t)(n_reads + 1) * 8 + (size_t)n_reads * 16;
@@ -941,7 +978,7 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
         if (ok) WDX_HIP_TRY(hipMemcpyAsync(B->in3.p, ok, (size_t)n_reads, hipMemcpyHostToDevice, s));
         Timed t(B, WDX_K_FINGERPRINT, s);
         if ((rc = launch_fingerprint((const float *)B->in0.p, d_off, d_len, 0, max_len, n_reads, d_as, d_ae,
-                                     ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p, nullptr, nullptr,
+                                     ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p, d_dwell, d_stats,
                                      (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches, nullptr, 0, 0, nullptr,
                                      &t.main, (double *)B->fp_big.p)))
             return rc;
@@ -958,7 +995,7 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
         if ((rc = launch_fingerprint(d_sig, nullptr, nullptr, stride, max_len, n_reads,
                                      (const int32_t *)B->in1.p, (const int32_t *)B->in2.p,
                                      ok ? (const uint8_t *)B->in3.p : nullptr, *p, (double *)B->out0.p,
-                                     nullptr, nullptr, (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches,
+                                     d_dwell, d_stats, (int32_t *)B->out3.p, s, B->fp_ws.p, B->knobs, &t.n_launches,
                                      nullptr, 0, 0, nullptr, &t.main, (double *)B->fp_big.p)))
             return rc;
     }
@@ -969,11 +1006,29 @@ static int demux_batch_enqueue(wdx_ctx *B, const DtwRefs &R, const float *sig, i
         if ((rc = launch_count_calls((int32_t *)B->out2.p, (const int32_t *)B->out3.p, n_reads, R.nY,
                                      nullptr, s)))
             return rc;
-        WDX_HIP_TRY(hipMemcpyAsync(h_call, B->out2.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
-        if (h_dist) WDX_HIP_TRY(hipMemcpyAsync(h_dist, B->out1.p, db, hipMemcpyDeviceToHost, s));
+        if (H.call) WDX_HIP_TRY(hipMemcpyAsync(H.call, B->out2.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+        if (H.dist) WDX_HIP_TRY(hipMemcpyAsync(H.dist, B->out1.p, db, hipMemcpyDeviceToHost, s));
+        if (svm) {
+            // the classifier tail on the distance rows that are on the device anyway (models/dtw_svm.py:90-93, models/utils.py:45-61);
+            // failed reads: pred -1, NaN probabilities (the reference never shows them to the model)
+            {
+                Timed t(B, WDX_K_SVM, s);
+                if ((rc = launch_svm_predict(*svm, (const float *)B->out1.p, n_reads, (double *)B->mb_prob.p,
+                                             (int32_t *)B->mb_pred.p, (double *)B->mb_conf.p, s, B->knobs)))
+                    return rc;
+            }
+            if ((rc = launch_svm_mask_failed((const int32_t *)B->out3.p, n_reads, svm->k, (double *)B->mb_prob.p,
+                                             (int32_t *)B->mb_pred.p, (double *)B->mb_conf.p, s)))
+                return rc;
+            if (H.prob) WDX_HIP_TRY(hipMemcpyAsync(H.prob, B->mb_prob.p, (size_t)n_reads * svm->k * 8, hipMemcpyDeviceToHost, s));
+            if (H.pred) WDX_HIP_TRY(hipMemcpyAsync(H.pred, B->mb_pred.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+            if (H.conf) WDX_HIP_TRY(hipMemcpyAsync(H.conf, B->mb_conf.p, (size_t)n_reads * 8, hipMemcpyDeviceToHost, s));
+        }
     }
-    WDX_HIP_TRY(hipMemcpyAsync(h_status, B->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
-    if (h_fpt) WDX_HIP_TRY(hipMemcpyAsync(h_fpt, B->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    WDX_HIP_TRY(hipMemcpyAsync(H.status, B->out3.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+    if (H.fpt) WDX_HIP_TRY(hipMemcpyAsync(H.fpt, B->out0.p, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    if (H.dwell) WDX_HIP_TRY(hipMemcpyAsync(H.dwell, d_dwell, (size_t)(n_reads * K) * 8, hipMemcpyDeviceToHost, s));
+    if (H.stats) WDX_HIP_TRY(hipMemcpyAsync(H.stats, d_stats, (size_t)n_reads * 48, hipMemcpyDeviceToHost, s));
     return WDX_SUCCESS;
 }
 
@@ -1016,8 +1071,13 @@ int wdx_demux_batch(wdx_ctx *ctx, const float *sig, int64_t n_reads, int64_t str
     hipStream_t s = ctx->stream;
     if ((rc = use_stream(ctx, s))) return rc;
     StreamDrain drain(s);
-    if ((rc = demux_batch_enqueue(ctx, ctx->refs, sig, n_reads, stride, a_start, a_end, ok, p, fpt, dist, call, status)))
-        return rc;
+    const wdx_minibatch_in in{sig, n_reads, stride, nullptr, nullptr, a_start, a_end, ok};
+    MbHostOut H;
+    H.status = status;
+    H.call = call;
+    H.dist = dist;
+    H.fpt = fpt;
+    if ((rc = demux_batch_enqueue(ctx, ctx->refs, in, p, H, nullptr))) return rc;
     WDX_HIP_TRY(hipStreamSynchronize(s));
     drain.done();
     if (ctx->refs.nY == 0)
@@ -1085,12 +1145,42 @@ int wdx_host_free(void *p) {
     return WDX_SUCCESS;
 }
 
-int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_reads, int64_t stride,
-                     const int32_t *a_start, const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
-                     int64_t n_refs, int32_t want_fpt, int32_t want_dist) {
+int wdx_demux_submit_ex(wdx_ctx *ctx, int32_t slot, const wdx_minibatch_in *in, const wdx_seg_params *p, int64_t n_refs,
+                        uint32_t want) {
     WDX_ENTER(ctx);
+    if (!in) {
+        set_error("demux_submit: null minibatch");
+        return WDX_ERR_INVALID;
+    }
     std::lock_guard<std::mutex> g(ctx->mu);
-    if ((rc = demux_check_args(ctx, "demux_submit", n_reads, stride, sig, a_start, a_end, p, n_refs))) return rc;
+    const int64_t n_reads = in->n_reads;
+    if ((rc = demux_check_args(ctx, "demux_submit", n_reads, in->row_off ? 0 : in->stride, in->sig, in->a_start, in->a_end, p,
+                               n_refs)))
+        return rc;
+    if (in->row_off) {  // packed rows: offsets ascending on 16-byte boundaries, every row inside its slice
+        if (n_reads > 0 && !in->row_len) {
+            set_error("demux_submit: packed rows need row_len");
+            return WDX_ERR_INVALID;
+        }
+        for (int64_t r = 0; r < n_reads; ++r) {
+            const int64_t o0 = in->row_off[r], o1 = in->row_off[r + 1];
+            if (o0 < 0 || (o0 & 3) || o1 < o0 || in->row_len[r] < 0 || (int64_t)in->row_len[r] > o1 - o0) {
+                set_error("demux_submit: packed row %lld: offsets must ascend in multiples of 4 and hold row_len samples", (long long)r);
+                return WDX_ERR_INVALID;
+            }
+        }
+    }
+    const bool want_svm = (want & WDX_WANT_SVM) != 0;
+    if (want_svm) {
+        if (!ctx->svm_set) {
+            set_error("demux_submit: WDX_WANT_SVM needs wdx_svm_set_model first");
+            return WDX_ERR_NO_REFS;
+        }
+        if (ctx->refs.nY != ctx->svm.n_train) {
+            set_error("reference set has %lld rows but the SVM was trained on %d", (long long)ctx->refs.nY, ctx->svm.n_train);
+            return WDX_ERR_INVALID;
+        }
+    }
     wdx_ctx *S = nullptr;
     if ((rc = slot_get(ctx, slot, &S))) return rc;
     if (S->slot_busy) {
@@ -1105,38 +1195,65 @@ int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_rea
     S->refs = ctx->refs;  // device pointers of the parent's resident set (read-only; wdx_set_refs drains the slots)
     const DtwRefs &R = ctx->refs;
     const int64_t K = p->barcode_num_events;
-    // page-locked output block of the slot: [fpt f64 n*K][dist f32 n*nY][call i32 n][status i32 n]
-    const size_t b_fpt = want_fpt ? (size_t)(n_reads * K) * 8 : 0;
-    const size_t b_dist = (want_dist && R.nY > 0) ? (size_t)(n_reads * R.nY) * 4 : 0;
-    const size_t b_i = (size_t)n_reads * 4;
-    S->slot_off[0] = 0;
-    S->slot_off[1] = b_fpt;
-    S->slot_off[2] = (b_fpt + b_dist + 7) / 8 * 8;
-    S->slot_off[3] = S->slot_off[2] + b_i;
-    if ((rc = S->pin_out.ensure(S->slot_off[3] + b_i + 8))) return rc;
+    const int64_t k = want_svm ? ctx->svm.k : 0;
+    // page-locked output block of the slot, 8-byte aligned pieces:
+    // [fpt f64 n*K][dwell i64 n*K][stats f64 n*6][prob f64 n*k][conf f64 n][dist f32 n*nY][call i32 n][status i32 n][pred i32 n]
+    const size_t n = (size_t)n_reads;
+    const size_t bytes[9] = {(want & WDX_WANT_FPT) ? n * K * 8 : 0,
+                             (want & WDX_WANT_DWELL) ? n * K * 8 : 0,
+                             (want & WDX_WANT_STATS) ? n * 48 : 0,
+                             want_svm ? n * (size_t)k * 8 : 0,
+                             want_svm ? n * 8 : 0,
+                             ((want & WDX_WANT_DIST) && R.nY > 0) ? n * (size_t)R.nY * 4 : 0,
+                             n * 4,
+                             n * 4,
+                             want_svm ? n * 4 : 0};
+    size_t off = 0;
+    for (int q = 0; q < 9; ++q) {
+        S->slot_off[q] = off;
+        off += (bytes[q] + 7) / 8 * 8;
+    }
+    if ((rc = S->pin_out.ensure(off + 8))) return rc;
     unsigned char *ho = (unsigned char *)S->pin_out.p;
     S->slot_n = n_reads;
     S->slot_K = K;
     S->slot_nY = R.nY;
-    S->slot_has_fpt = b_fpt != 0;
-    S->slot_has_dist = b_dist != 0;
+    S->slot_k = k;
+    S->slot_want = want & ~(bytes[5] ? 0u : WDX_WANT_DIST);
     if (n_reads == 0) {
         S->slot_busy = true;
         return WDX_SUCCESS;
     }
+    MbHostOut H;
+    H.fpt = bytes[0] ? (double *)(ho + S->slot_off[0]) : nullptr;
+    H.dwell = bytes[1] ? (int64_t *)(ho + S->slot_off[1]) : nullptr;
+    H.stats = bytes[2] ? (double *)(ho + S->slot_off[2]) : nullptr;
+    H.prob = bytes[3] ? (double *)(ho + S->slot_off[3]) : nullptr;
+    H.conf = bytes[4] ? (double *)(ho + S->slot_off[4]) : nullptr;
+    H.dist = bytes[5] ? (float *)(ho + S->slot_off[5]) : nullptr;
+    H.call = (int32_t *)(ho + S->slot_off[6]);
+    H.status = (int32_t *)(ho + S->slot_off[7]);
+    H.pred = bytes[8] ? (int32_t *)(ho + S->slot_off[8]) : nullptr;
     StreamDrain drain(S->stream);
-    if ((rc = demux_batch_enqueue(S, R, sig, n_reads, stride, a_start, a_end, ok, p,
-                                  b_fpt ? (double *)(ho + S->slot_off[0]) : nullptr,
-                                  b_dist ? (float *)(ho + S->slot_off[1]) : nullptr, (int32_t *)(ho + S->slot_off[2]),
-                                  (int32_t *)(ho + S->slot_off[3]))))
-        return rc;
+    if ((rc = demux_batch_enqueue(S, R, *in, p, H, want_svm ? &ctx->svm : nullptr))) return rc;
     drain.done();  // in flight on purpose: wdx_demux_wait synchronises
     S->slot_busy = true;
     return WDX_SUCCESS;
 }
 
-int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t *call, int32_t *status) {
+int wdx_demux_submit(wdx_ctx *ctx, int32_t slot, const float *sig, int64_t n_reads, int64_t stride,
+                     const int32_t *a_start, const int32_t *a_end, const uint8_t *ok, const wdx_seg_params *p,
+                     int64_t n_refs, int32_t want_fpt, int32_t want_dist) {
+    const wdx_minibatch_in in{sig, n_reads, stride, nullptr, nullptr, a_start, a_end, ok};
+    return wdx_demux_submit_ex(ctx, slot, &in, p, n_refs, (want_fpt ? WDX_WANT_FPT : 0u) | (want_dist ? WDX_WANT_DIST : 0u));
+}
+
+int wdx_demux_wait_ex(wdx_ctx *ctx, int32_t slot, const wdx_minibatch_out *out) {
     WDX_ENTER(ctx);
+    if (!out) {
+        set_error("demux_wait: null output block");
+        return WDX_ERR_INVALID;
+    }
     wdx_ctx *S = nullptr;
     {
         std::lock_guard<std::mutex> g(ctx->mu);
@@ -1151,11 +1268,14 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
             set_error("demux_wait: another thread is waiting on slot %d", (int)slot);
             return WDX_ERR_INVALID;
         }
-        if (S->slot_n > 0 && (!call || !status)) {
+        if (S->slot_n > 0 && (!out->call || !out->status)) {
             set_error("demux_wait: call and status are required");
             return WDX_ERR_INVALID;
         }
-        if (S->slot_n > 0 && ((fpt && !S->slot_has_fpt) || (dist && !S->slot_has_dist && S->slot_nY > 0))) {
+        const uint32_t w = S->slot_want;
+        if (S->slot_n > 0 && ((out->fpt && !(w & WDX_WANT_FPT)) || (out->dist && !(w & WDX_WANT_DIST) && S->slot_nY > 0) ||
+                              (out->dwell && !(w & WDX_WANT_DWELL)) || (out->stats && !(w & WDX_WANT_STATS)) ||
+                              ((out->prob || out->pred || out->conf) && !(w & WDX_WANT_SVM)))) {
             set_error("demux_wait: an output that was not requested at wdx_demux_submit");
             return WDX_ERR_INVALID;
         }
@@ -1173,12 +1293,27 @@ int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t
     const int64_t n = S->slot_n;
     if (n == 0) return WDX_SUCCESS;
     const unsigned char *ho = (const unsigned char *)S->pin_out.p;
-    memcpy(status, ho + S->slot_off[3], (size_t)n * 4);
-    if (S->slot_nY > 0) memcpy(call, ho + S->slot_off[2], (size_t)n * 4);
-    else for (int64_t r = 0; r < n; ++r) call[r] = -1;
-    if (fpt) memcpy(fpt, ho + S->slot_off[0], (size_t)(n * S->slot_K) * 8);
-    if (dist && S->slot_nY > 0) memcpy(dist, ho + S->slot_off[1], (size_t)(n * S->slot_nY) * 4);
+    const size_t nn = (size_t)n;
+    memcpy(out->status, ho + S->slot_off[7], nn * 4);
+    if (S->slot_nY > 0) memcpy(out->call, ho + S->slot_off[6], nn * 4);
+    else for (int64_t r = 0; r < n; ++r) out->call[r] = -1;
+    if (out->fpt) memcpy(out->fpt, ho + S->slot_off[0], nn * S->slot_K * 8);
+    if (out->dwell) memcpy(out->dwell, ho + S->slot_off[1], nn * S->slot_K * 8);
+    if (out->stats) memcpy(out->stats, ho + S->slot_off[2], nn * 48);
+    if (out->prob) memcpy(out->prob, ho + S->slot_off[3], nn * (size_t)S->slot_k * 8);
+    if (out->conf) memcpy(out->conf, ho + S->slot_off[4], nn * 8);
+    if (out->dist && S->slot_nY > 0) memcpy(out->dist, ho + S->slot_off[5], nn * S->slot_nY * 4);
+    if (out->pred) memcpy(out->pred, ho + S->slot_off[8], nn * 4);
     return WDX_SUCCESS;
+}
+
+int wdx_demux_wait(wdx_ctx *ctx, int32_t slot, double *fpt, float *dist, int32_t *call, int32_t *status) {
+    wdx_minibatch_out out{};
+    out.status = status;
+    out.call = call;
+    out.dist = dist;
+    out.fpt = fpt;
+    return wdx_demux_wait_ex(ctx, slot, &out);
 }
 
 int wdx_svm_set_model(wdx_ctx *ctx, const wdx_svm_model *m) {

@@ -71,9 +71,11 @@ struct wdx_ctx {
     // pipelined minibatches (wdx_demux_submit / wdx_demux_wait): up to WDX_MAX_SLOTS child contexts, each with its own stream and
     // workspaces, sharing this context's resident reference set; the fields below describe a child's batch in flight
     wdx_ctx *slots[WDX_MAX_SLOTS] = {};
-    bool slot_busy = false, slot_waiting = false, slot_has_fpt = false, slot_has_dist = false;
-    int64_t slot_n = 0, slot_K = 0, slot_nY = 0;
-    size_t slot_off[4] = {0, 0, 0, 0};
+    bool slot_busy = false, slot_waiting = false;
+    uint32_t slot_want = 0;  // WDX_WANT_* of the batch in flight
+    int64_t slot_n = 0, slot_K = 0, slot_nY = 0, slot_k = 0;
+    size_t slot_off[9] = {};  // fpt, dwell, stats, prob, conf, dist, call, status, pred in the slot's page-locked block
+    wdx::Buffer mb_dwell, mb_stats, mb_prob, mb_pred, mb_conf;  // device side of the optional minibatch outputs
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[wdx::kNumTimed];

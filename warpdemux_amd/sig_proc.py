@@ -363,12 +363,20 @@ def detect_results_to_fpt_batch(calibrated_signals, spc, detect_results: Sequenc
         fb = fingerprint_batch(calibrated_signals, a_s, a_e, params, success=ok, device=device)
     else:
         fb = fingerprint_refine_batch(calibrated_signals, a_s, a_e, params, refine, success=ok, device=device)
+    return read_results_from_batch(fb, detect_results, read_ids, refined=refine is not None)
+
+
+def read_results_from_batch(fb: FingerprintBatch, detect_results: Sequence, read_ids: Optional[Sequence[str]] = None,
+                            refined: bool = False) -> List[ReadResult]:
+    """The per-read ``ReadResult`` records of one fingerprinted minibatch (sig_proc.py:590-605 + the read id of
+    ``barcode_fpt_wrapper``, file_proc.py:216) -- shared by `detect_results_to_fpt_batch` and the feeder's workers."""
+    n = len(detect_results)
     out = []
     for i in range(n):
         st = int(fb.status[i])
         rid = None if read_ids is None else read_ids[i]
         extra = {}
-        if refine is not None and st in (0, 6):
+        if refined and st in (0, 6):
             q = fb.refine_idx[i]
             extra = dict(seg_cons_query_start=int(q[0]), seg_cons_query_end=int(q[1]), sig_barcode_start=int(q[2]))
         if st == 0 or st == 6:
