@@ -117,6 +117,7 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_NO_PEAK_FILTER 12      /* fast fingerprint kernels: no threshold filter of the peak list (every local maximum) */
 #define WDX_OPT_NO_WAVE_CLIP_LONG 13    /* windows beyond 6144 samples: clip bounds by the workgroup kernel alone (A/B, tests) */
 #define WDX_OPT_NO_CLIP_REUSE 14        /* exact kernel behind the launch chain: recompute the clip bounds (A/B, tests) */
+#define WDX_OPT_NO_SPLIT_TAIL 15        /* main fast fingerprint kernel in one piece: no tile kernel + tail kernel split (A/B, tests) */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,
@@ -481,6 +482,8 @@ int wdx_reduce_counts_host(wdx_ctx *ctx, int64_t *counts, int32_t n);
 #define WDX_K_REDUCE 5
 #define WDX_K_FINGERPRINT_MAIN 6 /* the main fast fingerprint kernel alone (WDX_K_FINGERPRINT = the whole chain) */
 #define WDX_K_FINGERPRINT_CLIP 7 /* clip_bounds_kernel alone (median / MAD / clip bounds ahead of the main kernel) */
+#define WDX_K_FINGERPRINT_TAIL 8 /* fingerprint_split_tail_kernel alone (the split main kernel's second half; its time is part of
+                                    WDX_K_FINGERPRINT_MAIN, which brackets the tile-kernel / tail-kernel launch pairs) */
 /* When enabled, every kernel launch through this context is bracketed by hipEvents on its
  * stream; wdx_kernel_time() synchronises them and returns accumulated ms and launch count. */
 int wdx_kernel_timing(wdx_ctx *ctx, int enable);

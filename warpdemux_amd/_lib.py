@@ -23,7 +23,7 @@ WDX_ERR_HIP = -3
 WDX_ERR_UNSUPPORTED = -4
 WDX_ERR_NO_REFS = -5
 
-K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE, K_FINGERPRINT_MAIN, K_FINGERPRINT_CLIP = 0, 1, 2, 3, 4, 5, 6, 7
+K_FINGERPRINT, K_DTW, K_TRANSPOSE, K_COUNT, K_SVM, K_REDUCE, K_FINGERPRINT_MAIN, K_FINGERPRINT_CLIP, K_FINGERPRINT_TAIL = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 # wdx_ctx_set_option selectors (diagnostics; the product path leaves all of them 0)
 OPT_EXACT_PATH, OPT_NO_WAVEFRONT_DTW, OPT_NO_SHORT_DTW, OPT_SVM_SCALAR, OPT_DEBUG_OCCUPANCY, OPT_FAST_PEAK_CAP = 1, 2, 3, 4, 5, 6
@@ -35,6 +35,7 @@ OPT_MAX_LAUNCH_SLICE = 11
 OPT_NO_PEAK_FILTER = 12
 OPT_NO_WAVE_CLIP_LONG = 13
 OPT_NO_CLIP_REUSE = 14
+OPT_NO_SPLIT_TAIL = 15
 COMM_ID_BYTES = 128
 ABI_VERSION = 4
 

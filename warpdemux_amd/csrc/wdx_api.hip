@@ -137,6 +137,9 @@ Timed::Timed(wdx_ctx *c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
         const auto q = take_event_pair(c);   // ... and a third around clip_bounds_kernel
         main.c_first = q.first;
         main.c_second = q.second;
+        // (the split main kernel asks for one more pair per tail-kernel launch)
+        main.take = [](void *arg) { return take_event_pair(static_cast<wdx_ctx *>(arg)); };
+        main.take_arg = c;
     }
 }
 
@@ -152,6 +155,10 @@ Timed::~Timed() {
         } else {
             c->pool.push_back({main.first, main.second});
         }
+    }
+    for (const auto &tp : main.tail) {
+        c->pending[WDX_K_FINGERPRINT_TAIL].push_back(tp);
+        c->pending_launches[WDX_K_FINGERPRINT_TAIL].push_back(1);
     }
     if (main.c_first) {
         if (main.c_recorded) {
@@ -439,6 +446,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_NO_PEAK_FILTER: ctx->knobs.no_peak_filter = value != 0; break;
         case WDX_OPT_NO_WAVE_CLIP_LONG: ctx->knobs.no_wave_clip_long = value != 0; break;
         case WDX_OPT_NO_CLIP_REUSE: ctx->knobs.no_clip_reuse = value != 0; break;
+        case WDX_OPT_NO_SPLIT_TAIL: ctx->knobs.no_split = value != 0; break;
         case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);

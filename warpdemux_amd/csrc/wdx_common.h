@@ -1,5 +1,7 @@
 // Shared declarations of the libwdx_hip translation units (internal; the public ABI is include/wdx.h).
 #pragma once
+#include <utility>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,6 +39,7 @@ struct Knobs {
     bool no_wave_clip_long = false;  // WDX_OPT_NO_WAVE_CLIP_LONG: long windows' clip bounds by clip_bounds_block_kernel alone
     bool no_peak_filter = false;     // WDX_OPT_NO_PEAK_FILTER: fast kernels append every local maximum (no threshold filter)
     int64_t max_launch_slice = 0;    // WDX_OPT_MAX_LAUNCH_SLICE: upper bound of one launch slice of the fingerprint chain (0 = built-in)
+    bool no_split = false;           // WDX_OPT_NO_SPLIT_TAIL: the main fast kernel in one piece (A/B, tests)
 };
 
 // A launch over more workgroups than grid.x admits is cut into slices (block_base != 0 from the second on).  The built-in
@@ -132,6 +135,11 @@ struct MainEvents {
     // a third pair around clip_bounds_kernel (WDX_K_FINGERPRINT_CLIP): the launch ahead of the main kernel
     hipEvent_t c_first = nullptr, c_second = nullptr;
     bool c_recorded = false;
+    // SPLIT main kernel: first / second bracket the whole sequence of (tile kernel, tail kernel) launch pairs; one more
+    // pair per slice around the tail kernel alone (WDX_K_FINGERPRINT_TAIL), taken from the context's pool through `take`
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tail;
+    std::pair<hipEvent_t, hipEvent_t> (*take)(void *) = nullptr;
+    void *take_arg = nullptr;
 };
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,

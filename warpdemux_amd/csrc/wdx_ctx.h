@@ -23,7 +23,7 @@ struct PinnedBuffer {  // grow-only page-locked host staging area
     void release();
 };
 
-constexpr int kNumTimed = 8;
+constexpr int kNumTimed = 9;
 
 // RAII: make the context's device current for the duration of one entry point and put the caller's
 // device back afterwards (a host thread that also drives torch must not find its device switched).

@@ -1584,6 +1584,7 @@ int64_t fingerprint_refine_ws_bytes(int64_t n_reads) { return (int64_t)sizeof(Re
 
 #endif  // WDX_DEV_KERNELS_ONLY
 #include "wdx_fingerprint_fast.inc"
+#include "wdx_fingerprint_split.inc"
 #ifndef WDX_DEV_KERNELS_ONLY
 
 static size_t fp_lds_bytes(int cap) {
@@ -1682,7 +1683,12 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
 }
 
 // eight counters (five used) | one ClipRec per read | five read lists (slow, big0, big1, retry, big2: see launch_fingerprint)
-int64_t fingerprint_workspace_bytes(int64_t n_reads) { return 32 + 40 * (n_reads > 0 ? n_reads : 0); }
+// | large batches: the split main kernel's peak lists for one launch slice (kSplitRecBytes per read, 16-byte aligned)
+static int64_t split_ws_offset(int64_t n_reads) { return (32 + 40 * (n_reads > 0 ? n_reads : 0) + 15) / 16 * 16; }
+int64_t fingerprint_workspace_bytes(int64_t n_reads) {
+    if (n_reads < 2048) return 32 + 40 * (n_reads > 0 ? n_reads : 0);
+    return split_ws_offset(n_reads) + (int64_t)kSplitRecBytes * std::min<int64_t>(n_reads, kSplitSlice);
+}
 
 // The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
@@ -1928,8 +1934,42 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                 main_ev->c_recorded = true;
             }
         }
+        // The SPLIT form of the RNA004 main kernel (large batches on approximate keys with the filtered 512-entry list): the
+        // workgroup-per-read kernel ends after the tile pass and exports the <= 256 peaks that can matter, one WAVE per read
+        // does the rest (fingerprint_split_tail_kernel) -- launch pairs over slices of kSplitSlice reads, whose lists live in
+        // the workspace behind the read lists.  Not for the diagnostic builds, the refinement branch, the six statistics or
+        // the median normalisation (the one-piece kernel serves those); n_reads >= 2048 is what sized the workspace.
+        const bool split = ext && approx && filt && combo == 1 && capF == 5120 && capP == 512 && chain && !d_prof && !rf &&
+                           !d_stats && p.seg_norm != WDX_NORM_MEDIAN && !knobs.no_split && n_reads >= 2048;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
-        launch_sliced(kern, F, n_reads, flds, true);
+        if (split) {
+            void (*kern_a)(FastArgs) = fingerprint_fast_kernel<kNptMid, false, kFW, 1, true, true>;
+            void (*kern_b)(FastArgs) = fingerprint_split_tail_kernel<kFW>;
+            static LdsAttr attr_split;
+            if (int rc = attr_split.ensure(kern_a, flds)) return rc;
+            F.split_ws = reinterpret_cast<unsigned char *>(d_ws) + split_ws_offset(n_reads);
+            const int64_t slice = launch_slice_limit(kSplitSlice);
+            for (int64_t base = 0; base < n_reads; base += slice) {
+                const int64_t m = std::min<int64_t>(slice, n_reads - base);
+                F.split_base = base;
+                F.split_n = m;
+                F.a.block_base = base;
+                hipLaunchKernelGGL(kern_a, dim3((unsigned)m), dim3(FB), flds, stream, F);
+                if (n_launches) ++*n_launches;
+                std::pair<hipEvent_t, hipEvent_t> tp{nullptr, nullptr};
+                if (main_ev && main_ev->first && main_ev->take) tp = main_ev->take(main_ev->take_arg);
+                if (tp.first) (void)hipEventRecord(tp.first, stream);
+                F.a.block_base = 0;
+                hipLaunchKernelGGL(kern_b, dim3((unsigned)((m + kSplitWaves - 1) / kSplitWaves)), dim3(kSplitWaves * 64), 0, stream, F);
+                if (tp.first) {
+                    (void)hipEventRecord(tp.second, stream);
+                    main_ev->tail.push_back(tp);
+                }
+            }
+            F.a.block_base = 0;
+        } else {
+            launch_sliced(kern, F, n_reads, flds, true);
+        }
         if (main_ev && main_ev->first) {
             (void)hipEventRecord(main_ev->second, stream);
             main_ev->recorded = true;
