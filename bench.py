@@ -906,6 +906,7 @@ def run_rank(args):
     fp_ms, fp_n = eng.kernel_time(_lib.K_FINGERPRINT)            # the whole fingerprint chain
     fpm_ms, fpm_n = eng.kernel_time(_lib.K_FINGERPRINT_MAIN)     # its main kernel's launches alone
     fpc_ms, fpc_n = eng.kernel_time(_lib.K_FINGERPRINT_CLIP)     # clip_bounds_kernel (median / MAD ahead of the main kernel)
+    fpt_ms, fpt_n = eng.kernel_time(_lib.K_FINGERPRINT_TAIL)     # split main kernel: its tail-kernel launches alone (part of MAIN)
     dtw_ms, dtw_n = eng.kernel_time(_lib.K_DTW)
     tr_ms, tr_n = eng.kernel_time(_lib.K_TRANSPOSE)
     cnt_ms, cnt_n = eng.kernel_time(_lib.K_COUNT)
@@ -947,6 +948,21 @@ def run_rank(args):
         main_samples = int(lens[fits].sum().item())
         main_bytes = 4.0 * main_samples + (8.0 * K_FPT + 4.0) * main_reads
         dom, dom_ms, dom_n, dom_bytes = "fingerprint_fast_kernel", fpm_ms, fpm_n, main_bytes
+        # Round 6: the main kernel is a PAIR per launch slice -- the workgroup-per-read tile kernel (fingerprint_fast_kernel<...,
+        # SPLIT>: load, clip, t-score tiles, peak list, export of <= 256 peaks with prefix sums) and the wave-per-read tail
+        # kernel (fingerprint_split_tail_kernel: suppression, top-E, boundaries, event means, normalisation, output).  The
+        # MAIN events bracket the pairs, the TAIL events the tail kernel alone; the dominant kernel is the tile kernel, priced
+        # on ITS algorithmic bytes (the samples it reads: 4 N per read -- the fingerprints are the tail kernel's output) over
+        # ITS time (MAIN - TAIL), the figure rocprofv3's average for that kernel must reproduce.
+        split_pair = None
+        if fpt_n > 0 and fpt_ms > 0:
+            split_pair = {"tile_kernel": "fingerprint_fast_kernel<20, false, 12, 1, true, true>", "tail_kernel": "fingerprint_split_tail_kernel<12>",
+                          "launch_pairs": fpm_n, "pair_ms_per_step": fpm_ms / steps, "tail_ms_per_step": fpt_ms / steps,
+                          "tile_ms_per_step": (fpm_ms - fpt_ms) / steps, "avg_tail_launch_ms": fpt_ms / fpt_n,
+                          "pair_algorithmic_bytes_per_step": main_bytes,
+                          "pair_achieved_gbs": main_bytes / (fpm_ms / steps * 1e-3) / 1e9,
+                          "pair_frac": main_bytes / (fpm_ms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            dom_ms, dom_bytes = fpm_ms - fpt_ms, 4.0 * main_samples
     else:
         dom, dom_ms, dom_n, dom_bytes = "dtw_band_kernel<15>", dtw_ms, dtw_n, dtw_bytes
     launches_per_step = max(dom_n // steps, 1)
@@ -1025,7 +1041,10 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": dom_n,
-                **({"kernel_instantiation": "fingerprint_fast_kernel<%d, false> (%d-sample windows)" % (main_cap // 256, main_cap),
+                **({"kernel_instantiation": ("fingerprint_fast_kernel<%d, false, 12, 1, true, true> (%d-sample windows; the tile kernel of the split "
+                                             "main pair: algorithmic bytes = the samples it reads)" % (main_cap // 256, main_cap)) if split_pair else
+                                            "fingerprint_fast_kernel<%d, false> (%d-sample windows)" % (main_cap // 256, main_cap),
+                    "split_main_pair": split_pair,
                     "reads_per_launch": main_reads / launches_per_step,
                     "share_of_reads": main_reads / n_reads,
                     "stage": {"what": "whole fingerprint chain (clip_bounds_kernel ahead of the main kernel + main kernel + "
@@ -1049,7 +1068,7 @@ def run_rank(args):
             },
             "kernels_ms_per_step": {   # HIP-event sums over all launches of a step (a step may be sliced)
                 "fingerprint": fp_ms / steps, "fingerprint_main_kernel": fpm_ms / steps,
-                "fingerprint_clip_kernel": fpc_ms / steps, "dtw": dtw_ms / steps,
+                "fingerprint_tail_kernel": fpt_ms / steps, "fingerprint_clip_kernel": fpc_ms / steps, "dtw": dtw_ms / steps,
                 "transpose": tr_ms / steps,
                 "count": cnt_ms / steps, "count_allreduce": red_ms / steps,
             },

@@ -1090,6 +1090,70 @@ def test_sliced_launches_of_a_30k_read_batch_vs_oracle(exact):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rna004", "no_norm", "reach9", "few_events", "quantised", "accept_less", "numpy1_clip"])
+def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
+    """Round 6: large RNA004 batches run the main fingerprint kernel as a PAIR -- the workgroup-per-read tile kernel exports
+    the <= 256 peaks that can matter with the prefix sums of the clipped samples at their boundaries, a wave-per-read tail
+    kernel does suppression / top-E / boundaries / event means / normalisation (wdx_fingerprint_split.inc).  Same decisions,
+    same arithmetic: fingerprints, dwell times and status must equal the one-piece kernel's (WDX_OPT_NO_SPLIT_TAIL) and the
+    oracle's bit for bit -- default parameters, no segment normalisation, the longest suppression reach of the
+    instantiation, few events on long windows (more than 256 peaks above the cut: the list kernel's turn), ADC-quantised
+    samples (ties and doubts: the retry and exact lists behind the tail kernel), accept_less_cpts, the NumPy-1.x clip rule --
+    in one launch pair and in slices of 1 000 reads."""
+    import torch
+
+    from warpdemux_amd.engine import DemuxEngine
+
+    kw = dict(barcode_num_events=110)
+    spec = synth.SynthSpec(n_barcodes=10)
+    n = 6_000
+    if case == "no_norm":
+        kw.update(seg_norm="none", barcode_num_events=25)
+    elif case == "reach9":
+        kw.update(min_obs_per_base=9, num_events=80, barcode_num_events=40)
+    elif case == "few_events":
+        kw.update(num_events=60, min_obs_per_base=3, barcode_num_events=25)
+    elif case == "quantised":
+        spec = synth.SynthSpec(n_barcodes=10, adc_quantum=2.0) if hasattr(synth.SynthSpec(), "adc_quantum") else spec
+    elif case == "accept_less":
+        kw.update(accept_less_cpts=True, num_events=125, barcode_num_events=25)
+    elif case == "numpy1_clip":
+        kw.update(clip_bounds="float64", outlier_thresh=2.7)
+    pt = sig_proc.SegParams(**kw)
+    K = pt.barcode_num_events
+    eng = DemuxEngine(np.zeros((2, K)), 15, 0.1, pt)
+    sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 3_000_000, n)
+    if case == "quantised" and not hasattr(synth.SynthSpec(), "adc_quantum"):
+        sig = torch.round(sig * 0.5) * 2.0      # a coarse 2 pA grid: plateaus and exact score ties at scale
+    got = {}
+    for name, opts in (("split", {}), ("split_sliced", {_lib.OPT_MAX_LAUNCH_SLICE: 1000}), ("one_piece", {_lib.OPT_NO_SPLIT_TAIL: 1})):
+        for o, v in opts.items():
+            eng.ctx.set_option(o, v)
+        try:
+            got[name] = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len, want_stats=False)
+            torch.cuda.synchronize()
+        finally:
+            for o in opts:
+                eng.ctx.set_option(o, 0)
+    for name in ("split_sliced", "one_piece"):
+        assert torch.equal(got[name][3], got["split"][3]), name
+        okd = got["split"][3] == 0
+        assert torch.equal(got[name][0][okd].view(torch.int64), got["split"][0][okd].view(torch.int64)), name
+        assert torch.equal(got[name][1][okd], got["split"][1][okd]), name
+    m = 1_500     # ... and the oracle on a quarter of them
+    fpt, dwell, stats, status = orc.fingerprint_packed(sig[: int(off[m].item())].cpu().numpy(), off[: m + 1].cpu().numpy().astype(np.int64),
+                                                       a_s[:m].cpu().numpy(), a_e[:m].cpu().numpy(), orc.SegParams(**{k: v for k, v in kw.items() if k != "clip_bounds"},
+                                                                                                                      **({"clip_bounds_f64": True} if case == "numpy1_clip" else {})))
+    st = got["split"][3][:m].cpu().numpy()
+    assert np.array_equal(st, status)
+    ok = status == 0
+    assert ok.mean() > (0.5 if case in ("few_events", "quantised") else 0.95)
+    assert np.array_equal(got["split"][0][:m].cpu().numpy()[ok].view(np.uint64), fpt[ok].view(np.uint64))
+    assert np.array_equal(got["split"][1][:m].cpu().numpy()[ok], dwell[ok])
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_fingerprint_mid_length_windows_take_the_8192_instantiation(monkeypatch):
     """Adapter windows of 6145..8192 samples are listed on the device by the 6144-sample fast kernel and
     retried by the 8192-sample one; longer ones (<= 11200) take the exact path.  All three must agree with

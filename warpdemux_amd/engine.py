@@ -96,13 +96,14 @@ class DemuxEngine:
             self._stream()))
         return out
 
-    def fingerprint(self, sig, a_start, a_end, *, offsets=None, stride=0, max_len: int, ok=None):
-        """Fingerprint stage only -> (fpt f64 (n,K), dwell i64 (n,K), stats f64 (n,6), status i32)."""
+    def fingerprint(self, sig, a_start, a_end, *, offsets=None, stride=0, max_len: int, ok=None, want_stats: bool = True):
+        """Fingerprint stage only -> (fpt f64 (n,K), dwell i64 (n,K), stats f64 (n,6) or None, status i32).  Without the six
+        statistics a large RNA004 batch takes the split main kernel (tile kernel + tail kernel), like `demux` does."""
         torch = self.torch
         n = int(a_start.shape[0])
         fpt = torch.empty((n, self.K), dtype=torch.float64, device=self.tdev)
         dwell = torch.empty((n, self.K), dtype=torch.int64, device=self.tdev)
-        stats = torch.empty((n, 6), dtype=torch.float64, device=self.tdev)
+        stats = torch.empty((n, 6), dtype=torch.float64, device=self.tdev) if want_stats else None
         status = torch.empty(n, dtype=torch.int32, device=self.tdev)
         pc = self.params.to_c()
         _lib.check(self.L.wdx_fingerprint_dev(
