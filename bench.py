@@ -448,8 +448,64 @@ def secondary_shipped_model_e2e(device):
             "accuracy_on_ok_reads": float((pred[okq] == bcq.cpu().numpy()[okq]).mean()), "ok_reads": int(okq.sum()),
             "parity": bool(err <= 1e-5 and same3 and np.array_equal(ost, status[:ns])), "max_abs_prob_err": err,
             "parity_tolerance": 1e-5, "parity_reads": ns}
-        del dfull, res, sgq
+        del dfull, res
         engm.close()
+        # ---- the TIMED half on the genuine model: the arrays of the reference's WDX10_rna004_v1_0.joblib (fixture g6b: 2 601 x
+        # 25 training fingerprints, every one a support vector, 11 classes, thresholds) resident instead of the model trained
+        # above -- same call, same reads; the model trained here stays as the accuracy leg (the synthetic reads mean nothing
+        # to the real model's barcodes).  Checked against the oracle (fingerprint -> DTW -> libsvm restatement) on 512 reads.
+        g6b = os.path.join(ROOT, "tests", "golden", "g6b_dtw_svm_wdx10.npz")
+        if os.path.exists(g6b):
+            g = np.load(g6b)
+            lm = {int(k): int(v) for k, v in zip(g["label_keys"], g["label_vals"])}
+            mr = DTW_SVM(g["X_train"], g["n_support"], g["support"], g["dual_coef"], -g["intercept"], g["probA"], g["probB"], lm,
+                         g["thresholds"], window=int(g["window"]), penalty=float(g["penalty"]), gamma=float(g["gamma"]),
+                         pwr_dist=int(g["pwr_dist"]), block_size=int(g["block_size"]), device=device)
+            engr = DemuxEngine(np.ascontiguousarray(g["X_train"], dtype=np.float64), int(g["window"]), float(g["penalty"]), pm, device=device)
+            engr.set_svm(mr)
+            resr = engr.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq)
+            for _ in range(2):
+                engr.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq, out=resr)
+            sync()
+            wr = []
+            engr.kernel_time_reset()
+            engr.kernel_timing(True)
+            for _ in range(5):
+                sync()
+                t0 = time.perf_counter()
+                engr.demux_svm(sgq, sq, eq, offsets=ofq, max_len=mlq, out=resr)
+                sync()
+                wr.append(time.perf_counter() - t0)
+            engr.kernel_timing(False)
+            kmr = {nm: engr.kernel_time(kid)[0] / 5 for nm, kid in (("fingerprint", _l.K_FINGERPRINT), ("dtw", _l.K_DTW),
+                                                                     ("transpose", _l.K_TRANSPOSE), ("svm_tail", _l.K_SVM))}
+            probr, predr, confr, statusr = (t.cpu().numpy() for t in resr[:4])
+            Dr = orc.dtw_matrix(ofp[oko], np.ascontiguousarray(g["X_train"], dtype=np.float64), int(g["window"]), float(g["penalty"]))
+            Kr = np.exp(-float(g["gamma"]) * np.power(Dr, int(g["pwr_dist"])))
+            pr = orc.svm_predict_proba(Kr, g["n_support"].astype(np.int32), g["support"].astype(np.int32), g["dual_coef"], -g["intercept"],
+                                       g["probA"], g["probB"])
+            errr = float(np.abs(probr[:ns][oko] - pr).max())
+            dtr = sum(wr) / len(wr)
+            synth_leg = {k: out["shipped_model_e2e"][k] for k in ("reads_per_s", "ms", "ms_min", "ms_max", "kernels_ms", "support_vectors",
+                                                                  "support_vectors_with_nonzero_coefficients", "accuracy_on_ok_reads",
+                                                                  "max_abs_prob_err", "useful_cell_updates_per_s")}
+            out["shipped_model_e2e"].update({
+                "workload": "wdx_demux_svm_dev on 100 000 device-resident synthetic reads against the REFERENCE's WDX10_rna004_v1_0 model (fixture "
+                            "g6b: 2 601 x 25-pt training fingerprints, every row a support vector, 11 classes, thresholds): fingerprint (K = 25) "
+                            "-> DTW with the SVM decision sums in the kernel's epilogue -> sigmoids, coupling, process_probs; no distance "
+                            "matrix.  `model_trained_here` = the same call on a model trained in this run on synthetic fingerprints (the "
+                            "accuracy leg: the synthetic barcodes mean nothing to the real model)",
+                "model": "WDX10_rna004_v1_0 (reference model file, tests/golden/g6b_dtw_svm_wdx10.npz)",
+                "reads_per_s": nq / dtr, "ms": dtr * 1e3, "ms_min": min(wr) * 1e3, "ms_max": max(wr) * 1e3, "reps": len(wr),
+                "kernels_ms": kmr, "support_vectors": int(g["support"].size), "useful_cell_updates_per_s": nq * 515.0 * g["X_train"].shape[0] / dtr,
+                "max_abs_prob_err": errr, "ok_reads": int((statusr == 0).sum()),
+                "parity": bool(out["shipped_model_e2e"]["parity"] and errr <= 1e-5 and np.array_equal(ost, statusr[:ns])),
+                "model_trained_here": synth_leg})
+            out["shipped_model_e2e"].pop("support_vectors_with_nonzero_coefficients", None)
+            out["shipped_model_e2e"].pop("accuracy_on_ok_reads", None)
+            del resr
+            engr.close()
+        del sgq
         out["shipped_model_e2e"]["reference_model"] = reference_model_parity(device)
         if out["shipped_model_e2e"]["reference_model"] is not None:
             out["shipped_model_e2e"]["parity"] = bool(out["shipped_model_e2e"]["parity"] and
@@ -561,7 +617,7 @@ def secondary_regimes(device):
     # page-locked ring -- always with the producers' own 40 MB fill per minibatch, like "pipe refill")
     # (most telling first: the leg stops launching once 20 s are spent and says which configurations it skipped)
     for mode, refill, P, jit in (("feeder", False, 16, 0), ("sync", False, 16, 0), ("sync", False, 4, 0), ("pipe", False, 1, 2900),
-                                 ("feeder", True, 16, 2900), ("feeder", False, 4, 0)):
+                                 ("feeder", True, 16, 2900), ("feeder_full", False, 16, 0), ("feeder", False, 4, 0)):
         key = "%s%s%s_P%d" % (mode, "_refill" if refill else "", "_jitter" if jit else "", P)
         cmd = [sys.executable, os.path.join(ROOT, "tools", "host_workers.py"), "--workers", str(P), "--mode", mode,
                "--seconds", "1.5", "--jitter", str(jit)] + (["--refill"] if refill else [])
@@ -581,8 +637,11 @@ def secondary_regimes(device):
                     "array, pipe = MinibatchPipeline (page-locked buffers, wdx_demux_submit / wdx_demux_wait); refill = the "
                     "worker copies a fresh minibatch into the buffer before every call; jitter = adapter_start ~ U{100..3000} per "
                     "read (rows carry whole reads; page-locked rows then go through the packed staging); feeder = warpdemux_amd.feeder.Feeder: one "
-                    "GPU-facing process serving a shared-memory ring of 8 minibatch slots (wdx_feeder_serve), the P workers call "
-                    "feeder.demux_batch like the sync mode calls sig_proc.demux_batch (wdx_feeder_demux: no context, no HIP call)",
+                    "GPU-facing process serving a shared-memory ring of 16 minibatch slots (wdx_feeder_serve; at most 8 in flight on the device), the P "
+                    "workers call feeder.demux_batch like the sync mode calls sig_proc.demux_batch (wdx_feeder_run: no context, no HIP call, only "
+                    "the adapter windows are copied into the ring); feeder_full = feeder.detect_and_predict: what the reference's worker needs "
+                    "from its minibatch (file_proc.py:380-454) -- fingerprints, dwell times, six statistics AND DTW_SVM.predict on the "
+                    "reference's WDX10_rna004_v1_0 model (2 601 x 25-pt training rows, 11 classes) -- from one pass",
         "host_cpus": effective_cores(), **hw,
         "best_reads_per_s": max((v["reads_per_s"] for v in good), default=None),
         "parity": bool(good) and all(v.get("parity") is True for v in hw.values() if "skipped" not in v)}

@@ -114,13 +114,69 @@ def feeder_mode(args):
 
     ctx = mp.get_context("fork")
     P = args.workers
-    refs = np.random.default_rng(0).normal(size=(N_REFS, K))
-    params = sig_proc.SegParams(barcode_num_events=K)
-    feeder = Feeder(refs, WINDOW, PENALTY, params, max_reads=N_READS, stride=STRIDE, n_slots=args.slots)
+    full = args.mode == "feeder_full"
+    if full:
+        # the reference worker's whole minibatch (file_proc.py:380-454): ReadResults' arrays AND DTW_SVM.predict, on the
+        # reference's own WDX10_rna004_v1_0 model (fixture g6b: 2 601 x 25-pt training fingerprints, 11 classes)
+        from warpdemux_amd.models import DTW_SVM
+
+        with np.load(os.path.join(ROOT, "tests", "golden", "g6b_dtw_svm_wdx10.npz")) as gz:
+            g = {k: gz[k] for k in gz.files}     # (read here: the forked workers would share the lazy archive's file offset)
+        lm = {int(k): int(v) for k, v in zip(g["label_keys"], g["label_vals"])}
+        model = DTW_SVM(g["X_train"], g["n_support"], g["support"], g["dual_coef"], -g["intercept"], g["probA"], g["probB"], lm,
+                        g["thresholds"], window=int(g["window"]), penalty=float(g["penalty"]), gamma=float(g["gamma"]),
+                        pwr_dist=int(g["pwr_dist"]), block_size=int(g["block_size"]))
+        KF = 25
+        params = sig_proc.SegParams(barcode_num_events=KF)
+        feeder = Feeder(model=model, params=params, max_reads=N_READS, stride=STRIDE, n_slots=args.slots)
+    else:
+        refs = np.random.default_rng(0).normal(size=(N_REFS, K))
+        params = sig_proc.SegParams(barcode_num_events=K)
+        feeder = Feeder(refs, WINDOW, PENALTY, params, max_reads=N_READS, stride=STRIDE, n_slots=args.slots)
     res_q = ctx.Queue()
     start = ctx.Barrier(P)
 
+    def producer_full(pid):
+        from oracle import wdx_oracle as orc
+        from warpdemux_amd import synth
+        try:
+            spec = synth.SynthSpec(n_barcodes=N_REFS)
+            mb, a_s, a_e, _ = synth.generate_minibatch(spec, 1000 * pid, N_READS, STRIDE, start_jitter=args.jitter)
+            src = mb.copy() if args.refill else None
+            for _ in range(2):
+                fb, (y_pred, y_prob) = feeder.detect_and_predict(mb, a_s, a_e)
+            start.wait()
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < args.seconds:
+                if src is not None:
+                    np.copyto(mb, src)                # the worker's own fill of its minibatch
+                fb, (y_pred, y_prob) = feeder.detect_and_predict(mb, a_s, a_e)
+                n += 1
+            dt = time.perf_counter() - t0
+            m = 64       # (the oracle's DTW against 2 601 references: a sample of the minibatch)
+            fpt, dwell, stats, status = orc.fingerprint_batch(mb[:m], a_s[:m], a_e[:m], orc.SegParams(barcode_num_events=KF))
+            okk = status == 0
+            D = orc.dtw_matrix(fpt[okk], np.ascontiguousarray(g["X_train"], dtype=np.float64), int(g["window"]), float(g["penalty"]))
+            Kq = np.exp(-float(g["gamma"]) * np.power(D, int(g["pwr_dist"])))
+            pr = orc.svm_predict_proba(Kq, g["n_support"].astype(np.int32), g["support"].astype(np.int32), g["dual_coef"],
+                                       -g["intercept"], g["probA"], g["probB"])
+            okf = fb.status == 0
+            rows = np.cumsum(okf) - 1       # row of read i among the successful ones
+            parity = bool(np.array_equal(fb.status[:m], status) and np.array_equal(fb.fpt[:m][okk].view(np.uint64), fpt[okk].view(np.uint64))
+                          and np.array_equal(fb.dwell[:m][okk], dwell[okk]) and np.array_equal(fb.stats[:m][okk].view(np.uint64), stats[okk].view(np.uint64))
+                          and np.abs(y_prob[rows[:m][okk]] - pr).max() <= 1e-5 and y_pred.shape[0] == int(okf.sum()))
+            res_q.put({"worker": pid, "minibatches": n, "seconds": dt, "parity": parity})
+        except Exception as e:  # noqa: BLE001
+            try:
+                start.abort()
+            except Exception:  # noqa: BLE001
+                pass
+            res_q.put({"error": f"producer {pid} {type(e).__name__}: {e}"})
+
     def producer(pid):
+        if full:
+            return producer_full(pid)
         from oracle import wdx_oracle as orc
         from warpdemux_amd import synth
         try:
@@ -169,7 +225,7 @@ def feeder_mode(args):
             return 1
         reads = sum(r["minibatches"] for r in res) * N_READS
         wall = max(r["seconds"] for r in res)
-        out = {"workers": P, "mode": "feeder", "slots": args.slots, "gpu_facing_processes": 1, "refill": bool(args.refill),
+        out = {"workers": P, "mode": args.mode, "slots": args.slots, "gpu_facing_processes": 1, "refill": bool(args.refill),
                "start_jitter": args.jitter, "reads_per_s": reads / wall, "minibatches": sum(r["minibatches"] for r in res),
                "seconds": wall, "ms_per_minibatch_per_worker": 1e3 * wall / (sum(r["minibatches"] for r in res) / P),
                "served_by_the_feeder": feeder.served(), "parity": all(r["parity"] for r in res)}
@@ -187,14 +243,15 @@ def feeder_mode(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", type=int, default=4)
-    ap.add_argument("--mode", choices=["sync", "pipe", "feeder"], default="sync")
+    ap.add_argument("--mode", choices=["sync", "pipe", "feeder", "feeder_full"], default="sync",
+                    help="feeder_full: feeder.detect_and_predict (fingerprints + dwell + statistics + DTW_SVM on the reference's WDX10 model)")
     ap.add_argument("--slots", type=int, default=16, help="feeder mode: ring slots (<= 32; at most 8 of them are in flight on the device)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--refill", action="store_true")
     ap.add_argument("--jitter", type=int, default=0, help="adapter_start ~ U{100 .. 100 + JITTER} per read (rows carry whole "
                     "reads, file_proc.py:244-260); 0 = every adapter starts at sample 100")
     args = ap.parse_args()
-    if args.mode == "feeder":
+    if args.mode in ("feeder", "feeder_full"):
         sys.exit(feeder_mode(args))
     ctx = mp.get_context("fork")      # the reference's start method (file_proc.py:1197)
     barrier = ctx.Barrier(args.workers)
