@@ -181,6 +181,27 @@ def test_refinement_parameters_validate_like_the_reference():
         sig_proc.RefineParams.from_spc(spc, q).to_c()
 
 
+def test_a_configuration_that_admits_windows_beyond_the_engines_cap_is_refused_once():
+    """adapter windows beyond WDX_MAX_ADAPTER_SAMPLES come back status 5 from the kernels, where the
+    reference (sig_proc.py:382-391) fingerprints any length.  `--export core.max_obs_trace=...` is what makes such windows
+    possible: SegParams.from_spc -- the start of every shim that takes the reference's config -- refuses that
+    configuration with the limit in the message; the shipped values (10 000 / 15 000 + 2 x 100) pass."""
+    from types import SimpleNamespace as NS
+
+    seg = NS(min_obs_per_base=6, running_stat_width=12, num_events=110, accept_less_cpts=False, normalization="mean",
+             barcode_num_events=25, consensus_refinement=False)
+    for mot in (10000, 15000, 16184):
+        spc = NS(sig_extract=NS(padding=100, normalization="none"), core=NS(sig_norm_outlier_thresh=5.0, max_obs_trace=mot), segmentation=seg)
+        assert sig_proc.SegParams.from_spc(spc).num_events == 110
+    spc = NS(sig_extract=NS(padding=100, normalization="none"), core=NS(sig_norm_outlier_thresh=5.0, max_obs_trace=16185), segmentation=seg)
+    with pytest.raises(NotImplementedError, match="16384"):
+        sig_proc.SegParams.from_spc(spc)
+    with pytest.raises(NotImplementedError, match="max_obs_trace = 40000"):
+        sig_proc.detect_results_to_fpt_batch(np.zeros((1, 100), np.float32), NS(sig_extract=NS(padding=100, normalization="none"),
+                                             core=NS(sig_norm_outlier_thresh=5.0, max_obs_trace=40000), segmentation=seg),
+                                             [sig_proc.DetectResults(True, "", 0, 50)])
+
+
 def _feeder_ring(n_slots=2, max_reads=10, max_stride=100, n_refs=4, n_events=0, n_classes=0, K=25):
     import ctypes as C
     import mmap

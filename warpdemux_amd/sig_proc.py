@@ -20,6 +20,8 @@ import numpy as np
 
 from . import _lib
 
+MAX_ADAPTER_SAMPLES = 16384   # WDX_MAX_ADAPTER_SAMPLES (include/wdx.h)
+
 # status code -> ReadResult.fail_reason (reference strings: sig_proc.py:400-407, 440-446, 538-544,
 # 554-560; file_proc.py:224).  Codes 2 and 4 carry the exception text in the reference; the only
 # exception reachable there is mean/mad_normalize's ValueError("Signal contains NaN values.").
@@ -66,6 +68,16 @@ class SegParams:
             k = int(k[1])
         elif not isinstance(k, (int, np.integer)):
             raise ValueError("barcode_num_events must be an int outside consensus refinement mode")
+        # The engine takes adapter windows of at most WDX_MAX_ADAPTER_SAMPLES = 16 384 samples (the shipped configs admit
+        # max_obs_trace + 2 * padding = 10 200 / 15 200); the reference has no such limit (sig_proc.py:382-391).  A
+        # configuration that admits longer windows (`--export core.max_obs_trace=...`) is refused HERE, once, instead of
+        # every such read coming back "unknown" from the kernels.
+        mot = getattr(getattr(spc, "core", None), "max_obs_trace", None)
+        if isinstance(mot, (int, np.integer)) and int(mot) + 2 * int(spc.sig_extract.padding) > MAX_ADAPTER_SAMPLES:
+            raise NotImplementedError(
+                f"core.max_obs_trace = {int(mot)} with padding {int(spc.sig_extract.padding)} admits adapter windows of "
+                f"{int(mot) + 2 * int(spc.sig_extract.padding)} samples; the HIP engine takes at most {MAX_ADAPTER_SAMPLES} "
+                "(WDX_MAX_ADAPTER_SAMPLES)")
         return cls(
             padding=int(spc.sig_extract.padding),
             sig_norm=str(spc.sig_extract.normalization),
