@@ -1090,7 +1090,7 @@ def test_sliced_launches_of_a_30k_read_batch_vs_oracle(exact):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["rna004", "no_norm", "reach9", "few_events", "quantised", "accept_less", "numpy1_clip"])
+@pytest.mark.parametrize("case", ["rna004", "no_norm", "reach9", "few_events", "quantised", "accept_less", "numpy1_clip", "mixed_failures"])
 def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
     """Round 6: large RNA004 batches run the main fingerprint kernel as a PAIR -- the workgroup-per-read tile kernel exports
     the <= 256 peaks that can matter with the prefix sums of the clipped samples at their boundaries, a wave-per-read tail
@@ -1125,12 +1125,28 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
     sig, off, a_s, a_e, bc, max_len = eng.synth_packed(spec, 3_000_000, n)
     if case == "quantised" and not hasattr(synth.SynthSpec(), "adc_quantum"):
         sig = torch.round(sig * 0.5) * 2.0      # a coarse 2 pA grid: plateaus and exact score ties at scale
+    okm = None
+    if case == "mixed_failures":
+        # every way a read leaves the split pair early: failed detection, a window too short to segment, a NaN and a negative
+        # sample in the window (the clip record refuses: exact kernel), windows cut short -- the tail kernel must not pick up
+        # the previous occupant of such a read's list slot (slices of 1 000 reads reuse the slots six times)
+        okm = torch.ones(n, dtype=torch.uint8, device=sig.device)
+        okm[5::97] = 0
+        a_e = a_e.clone()
+        a_e[11::101] = a_s[11::101] + 40             # window = 240 samples: below every kernel's minimum
+        a_e[17::103] = a_s[17::103] + 900            # short window: parameters shrink (sig_proc.py:526-533) -> exact kernel
+        sig = sig.clone()
+        offh = off.cpu().numpy()
+        for r in range(23, n, 107):
+            sig[int(offh[r]) + 700] = float("nan")
+        for r in range(29, n, 109):
+            sig[int(offh[r]) + 900] = -3.0
     got = {}
     for name, opts in (("split", {}), ("split_sliced", {_lib.OPT_MAX_LAUNCH_SLICE: 1000}), ("one_piece", {_lib.OPT_NO_SPLIT_TAIL: 1})):
         for o, v in opts.items():
             eng.ctx.set_option(o, v)
         try:
-            got[name] = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len, want_stats=False)
+            got[name] = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len, want_stats=False, ok=okm)
             torch.cuda.synchronize()
         finally:
             for o in opts:
@@ -1144,10 +1160,14 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
     fpt, dwell, stats, status = orc.fingerprint_packed(sig[: int(off[m].item())].cpu().numpy(), off[: m + 1].cpu().numpy().astype(np.int64),
                                                        a_s[:m].cpu().numpy(), a_e[:m].cpu().numpy(), orc.SegParams(**{k: v for k, v in kw.items() if k != "clip_bounds"},
                                                                                                                       **({"clip_bounds_f64": True} if case == "numpy1_clip" else {})))
+    if okm is not None:     # (the packed oracle entry point has no success flags: a failed detection is status 1, sig_proc.py:400-407)
+        status[okm[:m].cpu().numpy() == 0] = 1
     st = got["split"][3][:m].cpu().numpy()
     assert np.array_equal(st, status)
     ok = status == 0
-    assert ok.mean() > (0.5 if case in ("few_events", "quantised") else 0.95)
+    assert ok.mean() > (0.5 if case in ("few_events", "quantised") else 0.9)
+    if case == "mixed_failures":
+        assert set(np.unique(status).tolist()) >= {0, 1}, np.unique(status)
     assert np.array_equal(got["split"][0][:m].cpu().numpy()[ok].view(np.uint64), fpt[ok].view(np.uint64))
     assert np.array_equal(got["split"][1][:m].cpu().numpy()[ok], dwell[ok])
     eng.close()

@@ -1996,7 +1996,28 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             FastArgs F1{A, capF1, capP1f, count, list, with_stream ? count + 4 : (with_big1 ? count + 2 : nullptr),
                         with_stream ? big2 : (with_big1 ? big1 : nullptr), count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
             if (int rc = launch_clip_bounds_list(A, clip, count + 1, big0, g1, stream)) return rc;
-            launch_sliced(kern_l1, F1, g1, flds1f, false);
+            if (split) {
+                // the same pair over the list's entries (slot = workgroup of the slice; most of the grid lies past the list's end
+                // and leaves at once, in both kernels)
+                void (*kern_a1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge, kFW, 1, true>;
+                void (*kern_b)(FastArgs) = fingerprint_split_tail_kernel<kFW>;
+                static LdsAttr attr_split1;
+                if (int rc = attr_split1.ensure(kern_a1, flds1f)) return rc;
+                F1.split_ws = F.split_ws;
+                const int64_t slice = launch_slice_limit(kSplitSlice);
+                for (int64_t base = 0; base < g1; base += slice) {
+                    const int64_t m = std::min<int64_t>(slice, g1 - base);
+                    F1.split_base = base;
+                    F1.split_n = m;
+                    F1.a.block_base = base;
+                    hipLaunchKernelGGL(kern_a1, dim3((unsigned)m), dim3(FB), flds1f, stream, F1);
+                    F1.a.block_base = 0;
+                    hipLaunchKernelGGL(kern_b, dim3((unsigned)((m + kSplitWaves - 1) / kSplitWaves)), dim3(kSplitWaves * 64), 0, stream, F1);
+                }
+                F1.a.block_base = 0;
+            } else {
+                launch_sliced(kern_l1, F1, g1, flds1f, false);
+            }
             if (g1 < n_reads) {
                 FastArgs F1b{A, capF2, capP2f, count, list, with_stream ? count + 4 : nullptr, with_stream ? big2 : nullptr,
                              count + 1, big0, (unsigned)g1, F.retry_count, F.retry_list, nullptr};
