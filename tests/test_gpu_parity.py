@@ -1090,7 +1090,8 @@ def test_sliced_launches_of_a_30k_read_batch_vs_oracle(exact):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["rna004", "no_norm", "reach9", "few_events", "quantised", "accept_less", "numpy1_clip", "mixed_failures"])
+@pytest.mark.parametrize("case", ["rna004", "no_norm", "reach9", "few_events", "quantised", "accept_less", "numpy1_clip", "mixed_failures",
+                                  "with_stats", "median_norm", "rna002_triple", "trna_triple", "w12_reach17", "w24_stats"])
 def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
     """Round 6: large RNA004 batches run the main fingerprint kernel as a PAIR -- the workgroup-per-read tile kernel exports
     the <= 256 peaks that can matter with the prefix sums of the clipped samples at their boundaries, a wave-per-read tail
@@ -1119,6 +1120,17 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
         kw.update(accept_less_cpts=True, num_events=125, barcode_num_events=25)
     elif case == "numpy1_clip":
         kw.update(clip_bounds="float64", outlier_thresh=2.7)
+    elif case == "median_norm":
+        kw.update(seg_norm="median", barcode_num_events=25)
+    elif case == "rna002_triple":       # NBT = 2: the tail kernel's 20-peak windows (lanes +-1 by DPP, +-2 by ds_bpermute)
+        kw.update(num_events=110, min_obs_per_base=15, running_stat_width=30, barcode_num_events=25)
+    elif case == "trna_triple":
+        kw.update(num_events=120, min_obs_per_base=9, running_stat_width=18, barcode_num_events=25)
+    elif case == "w12_reach17":
+        kw.update(num_events=110, min_obs_per_base=12, running_stat_width=12, barcode_num_events=25)
+    elif case == "w24_stats":
+        kw.update(num_events=110, min_obs_per_base=12, running_stat_width=24, barcode_num_events=40)
+    want_stats = case in ("with_stats", "median_norm", "w24_stats", "rna002_triple")
     pt = sig_proc.SegParams(**kw)
     K = pt.barcode_num_events
     eng = DemuxEngine(np.zeros((2, K)), 15, 0.1, pt)
@@ -1146,7 +1158,7 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
         for o, v in opts.items():
             eng.ctx.set_option(o, v)
         try:
-            got[name] = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len, want_stats=False, ok=okm)
+            got[name] = eng.fingerprint(sig, a_s, a_e, offsets=off, max_len=max_len, want_stats=want_stats, ok=okm)
             torch.cuda.synchronize()
         finally:
             for o in opts:
@@ -1156,6 +1168,8 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
         okd = got["split"][3] == 0
         assert torch.equal(got[name][0][okd].view(torch.int64), got["split"][0][okd].view(torch.int64)), name
         assert torch.equal(got[name][1][okd], got["split"][1][okd]), name
+        if want_stats:
+            assert torch.equal(got[name][2][okd].view(torch.int64), got["split"][2][okd].view(torch.int64)), name
     m = 1_500     # ... and the oracle on a quarter of them
     fpt, dwell, stats, status = orc.fingerprint_packed(sig[: int(off[m].item())].cpu().numpy(), off[: m + 1].cpu().numpy().astype(np.int64),
                                                        a_s[:m].cpu().numpy(), a_e[:m].cpu().numpy(), orc.SegParams(**{k: v for k, v in kw.items() if k != "clip_bounds"},
@@ -1170,6 +1184,8 @@ def test_split_main_kernel_equals_the_one_piece_kernel_and_the_oracle(case):
         assert set(np.unique(status).tolist()) >= {0, 1}, np.unique(status)
     assert np.array_equal(got["split"][0][:m].cpu().numpy()[ok].view(np.uint64), fpt[ok].view(np.uint64))
     assert np.array_equal(got["split"][1][:m].cpu().numpy()[ok], dwell[ok])
+    if want_stats:
+        assert np.array_equal(got["split"][2][:m].cpu().numpy()[ok].view(np.uint64), stats[ok].view(np.uint64))
     eng.close()
 
 

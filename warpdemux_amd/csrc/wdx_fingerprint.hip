@@ -1821,6 +1821,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // the streaming form)
         const bool filt = approx && !knobs.no_peak_filter;   // (the launches on approximate keys below)
         if (ext && filt && nbt == 1 && capF <= 5120) capP = 512;
+        // the NBT = 2 widths' 6144-sample main kernel at FIVE workgroups per CU: 96 VGPRs (launch bound) and the filtered
+        // 512-entry list -- 31 000 B of LDS (five need <= 32 000); longer lists move on to the list kernel
+        // (not width 6: its reach-3 lists are the longest -- 512 entries overflow for most reads, 23.3 -> 22.8 M reads/s)
+        if (ext && filt && nbt == 2 && capF == 6144 && kWideWgPerCu == 5 && p.running_stat_width >= 12) capP = 512;
         if (knobs.fast_peak_cap > 0) capP = knobs.fast_peak_cap;  // experiment knob (wdx_ctx_set_option)
         const size_t flds = fast_lds_bytes(capF, capP, nbt);
         unsigned *count = reinterpret_cast<unsigned *>(d_ws);  // [0] slow, [1] big0, [2] big1, [3] retry, [4] big2, [5] back
@@ -1858,6 +1862,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         void (*kern_st)(FastArgs) = combo == 2 ? fingerprint_fast_stream_kernel<18, 1>
                                     : (combo == 3 ? fingerprint_fast_stream_kernel<30, 2> : fingerprint_fast_stream_kernel<kFW, 1>);
         void (*kern)(FastArgs) = nullptr;
+        // the SPLIT pair of the main launch (tile kernel + tail kernel) and of the 6144-sample list launch, where they exist
+        void (*kern_a)(FastArgs) = nullptr, (*kern_b)(FastArgs) = nullptr, (*kern_a1)(FastArgs) = nullptr;
         void (*kern_l1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge>;   // 6144 samples, one workgroup per entry
         void (*kern_ls)(FastArgs) = fingerprint_fast_list_kernel<kNptHuge>;     // 8192 samples, striding
         int slot = 0;
@@ -1869,6 +1875,10 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, FWx, 2>;
             kern_st = fingerprint_fast_stream_kernel<FWx, 2>;
             slot = 2;
+            if constexpr (FWx >= 12) {   // (the widths whose EXT main kernel runs the filtered 512-entry list)
+                kern_a = fingerprint_fast_kernel<kNptLarge, false, FWx, 2, true, true>;
+                kern_b = fingerprint_split_tail_kernel<FWx, 2>;
+            }
         };
         if (combo == 2) {
             kern = capF == 5120 ? fingerprint_fast_kernel<kNptMid, false, 18, 1, true>
@@ -1877,6 +1887,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             kern_l1 = fingerprint_fast_list1_kernel<kNptLarge, 18, 1>;
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, 18, 1>;
             slot = capF == 5120 ? 1 : 2;
+            if (capF == 5120) {
+                kern_a = fingerprint_fast_kernel<kNptMid, false, 18, 1, true, true>;
+                kern_b = fingerprint_split_tail_kernel<18, 1>;
+                kern_a1 = fingerprint_fast_list1_kernel<kNptLarge, 18, 1, true>;
+            }
         } else if (combo == 3) {
             wide_set(std::integral_constant<int, 30>{});
         } else if (combo == 4) {
@@ -1895,6 +1910,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         } else if (capF == 5120) {
             kern = d_prof ? fingerprint_fast_kernel<kNptMid, true, kFW, 1, true> : fingerprint_fast_kernel<kNptMid, false, kFW, 1, true>;
             slot = 1;
+            kern_a = fingerprint_fast_kernel<kNptMid, false, kFW, 1, true, true>;
+            kern_b = fingerprint_split_tail_kernel<kFW, 1>;
+            kern_a1 = fingerprint_fast_list1_kernel<kNptLarge, kFW, 1, true>;
         } else {
             kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptLarge, true, kFW, 1, true> : fingerprint_fast_kernel<kNptLarge, false, kFW, 1, true>)
                        : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
@@ -1934,19 +1952,16 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                 main_ev->c_recorded = true;
             }
         }
-        // The SPLIT form of the RNA004 main kernel (large batches on approximate keys with the filtered 512-entry list): the
-        // workgroup-per-read kernel ends after the tile pass and exports the <= 256 peaks that can matter, one WAVE per read
-        // does the rest (fingerprint_split_tail_kernel) -- launch pairs over slices of kSplitSlice reads, whose lists live in
-        // the workspace behind the read lists.  Not for the diagnostic builds, the refinement branch, the six statistics or
-        // the median normalisation (the one-piece kernel serves those); n_reads >= 2048 is what sized the workspace.
-        const bool split = ext && approx && filt && combo == 1 && capF == 5120 && capP == 512 && chain && !d_prof && !rf &&
-                           !d_stats && p.seg_norm != WDX_NORM_MEDIAN && !knobs.no_split && n_reads >= 2048;
+        // The SPLIT form of the main kernel (large batches on approximate keys with the filtered 512-entry list -- the RNA004
+        // triple, width 18, and the NBT = 2 widths from 12 up): the workgroup-per-read kernel ends after the tile pass and exports
+        // the <= 256 peaks that can matter, one WAVE per read does the rest (fingerprint_split_tail_kernel) -- launch pairs over
+        // slices of kSplitSlice reads, whose lists live in the workspace behind the read lists.  Not for the diagnostic builds
+        // or the refinement branch (the one-piece kernel serves those); n_reads >= 2048 is what sized the workspace.
+        const bool split = kern_a && ext && approx && filt && capP == 512 && chain && !d_prof && !rf && !knobs.no_split && n_reads >= 2048;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         if (split) {
-            void (*kern_a)(FastArgs) = fingerprint_fast_kernel<kNptMid, false, kFW, 1, true, true>;
-            void (*kern_b)(FastArgs) = fingerprint_split_tail_kernel<kFW>;
-            static LdsAttr attr_split;
-            if (int rc = attr_split.ensure(kern_a, flds)) return rc;
+            static LdsAttr attr_split[8];
+            if (int rc = attr_split[combo - 1].ensure(kern_a, flds)) return rc;
             F.split_ws = reinterpret_cast<unsigned char *>(d_ws) + split_ws_offset(n_reads);
             const int64_t slice = launch_slice_limit(kSplitSlice);
             for (int64_t base = 0; base < n_reads; base += slice) {
@@ -1996,13 +2011,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             FastArgs F1{A, capF1, capP1f, count, list, with_stream ? count + 4 : (with_big1 ? count + 2 : nullptr),
                         with_stream ? big2 : (with_big1 ? big1 : nullptr), count + 1, big0, 0u, F.retry_count, F.retry_list, clip};
             if (int rc = launch_clip_bounds_list(A, clip, count + 1, big0, g1, stream)) return rc;
-            if (split) {
+            if (split && kern_a1 && capP1f == 512) {
                 // the same pair over the list's entries (slot = workgroup of the slice; most of the grid lies past the list's end
                 // and leaves at once, in both kernels)
-                void (*kern_a1)(FastArgs) = fingerprint_fast_list1_kernel<kNptLarge, kFW, 1, true>;
-                void (*kern_b)(FastArgs) = fingerprint_split_tail_kernel<kFW>;
-                static LdsAttr attr_split1;
-                if (int rc = attr_split1.ensure(kern_a1, flds1f)) return rc;
+                static LdsAttr attr_split1[8];
+                if (int rc = attr_split1[combo - 1].ensure(kern_a1, flds1f)) return rc;
                 F1.split_ws = F.split_ws;
                 const int64_t slice = launch_slice_limit(kSplitSlice);
                 for (int64_t base = 0; base < g1; base += slice) {
