@@ -683,7 +683,8 @@ def secondary_regimes(device):
                       "parity_reads": ns_,
                       "parity": bool(np.array_equal(g[3][:ns_].cpu().numpy(), ostat) and
                                      np.array_equal(g[0][:ns_].cpu().numpy()[okt].view(np.uint64), ofp[okt].view(np.uint64)) and
-                                     np.array_equal(g[1][:ns_].cpu().numpy()[okt], odw[okt]))}
+                                     np.array_equal(g[1][:ns_].cpu().numpy()[okt], odw[okt]) and
+                                     np.array_equal(g[2][:ns_].cpu().numpy()[okt].view(np.uint64), ost[okt].view(np.uint64)))}
         del sg, of, s0, e0, g
         engt.close()
     try:
