@@ -1684,11 +1684,15 @@ int launch_score_selftest(const double *dm, const double *vs, int64_t n, double 
 
 // eight counters (five used) | one ClipRec per read | five read lists (slow, big0, big1, retry, big2: see launch_fingerprint)
 // | large batches: the split main kernel's peak lists for one launch slice (kSplitRecBytes per read, 16-byte aligned)
+// | 16 diagnostic counters (WDX_OPT_DEBUG_OCCUPANCY: why reads were handed to the exact kernel) at the very end -- in the
+// caller's workspace, i.e. per context and per call, ordered by the call's stream
 static int64_t split_ws_offset(int64_t n_reads) { return (32 + 40 * (n_reads > 0 ? n_reads : 0) + 15) / 16 * 16; }
-int64_t fingerprint_workspace_bytes(int64_t n_reads) {
-    if (n_reads < 2048) return 32 + 40 * (n_reads > 0 ? n_reads : 0);
-    return split_ws_offset(n_reads) + (int64_t)kSplitRecBytes * std::min<int64_t>(n_reads, kSplitSlice);
+static int64_t dbg_ws_offset(int64_t n_reads) {
+    // (the lists of one slice for every batch size: 4.6 KB per read -- the launch chain is for batches of 2048 reads and
+    // more by default, but WDX_OPT_FAST_CHAIN_MIN_READS sends smaller ones through it: the randomised parameter tests)
+    return split_ws_offset(n_reads) + (int64_t)kSplitRecBytes * std::min<int64_t>(n_reads > 0 ? n_reads : 0, kSplitSlice);
 }
+int64_t fingerprint_workspace_bytes(int64_t n_reads) { return dbg_ws_offset(n_reads) + 64; }
 
 // The fast kernels exist for three (window width, suppression reach) combinations -- the shipped parameter triples:
 //   1: W = 12, d <= 9  (RNA004: 110, 6, 12)      every instantiation of the launch chain
@@ -1840,9 +1844,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool with_big1 = chain && capF >= 5120 && cap > 6144 && !with_stream;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
         A.peak_filter = knobs.no_peak_filter ? 0 : 1;   // (only the approximate-keys launches look at it)
-        static unsigned *d_reasons = nullptr;   // (diagnostic: one buffer per process, zeroed per call)
-        if (knobs.debug_occ) {
-            if (!d_reasons) WDX_HIP_TRY(hipMalloc(&d_reasons, 64));
+        unsigned *d_reasons = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(d_ws) + dbg_ws_offset(n_reads));
+        if (knobs.debug_occ) {   // (diagnostic: 16 counters at the end of this call's workspace, zeroed on its stream)
             WDX_HIP_TRY(hipMemsetAsync(d_reasons, 0, 64, stream));
             A.dbg_reasons = d_reasons;
         }
@@ -1956,9 +1959,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // triple, width 18, and the NBT = 2 widths from 12 up): the workgroup-per-read kernel ends after the tile pass and exports
         // the <= 256 peaks that can matter, one WAVE per read does the rest (fingerprint_split_tail_kernel) -- launch pairs over
         // slices of kSplitSlice reads, whose lists live in the workspace behind the read lists.  Not for the diagnostic builds
-        // (the one-piece kernel serves those); n_reads >= 2048 is what sized the workspace.
+        // (the one-piece kernel serves those).
         // (not the refinement branch: measured 2.36 against 2.15 ms per 32 768 tRNA-like reads with the one-piece kernel)
-        const bool split = kern_a && ext && approx && filt && capP == 512 && chain && !d_prof && !rf && !knobs.no_split && n_reads >= 2048;
+        const bool split = kern_a && ext && approx && filt && capP == 512 && chain && !d_prof && !rf && !knobs.no_split;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         if (split) {
             static LdsAttr attr_split[8];
@@ -2157,7 +2160,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                     c[4], c[3], c[0]);
             {
                 unsigned h[16];
-                WDX_HIP_TRY(hipMemcpy(h, d_reasons, 64, hipMemcpyDeviceToHost));
+                WDX_HIP_TRY(hipMemcpyAsync(h, d_reasons, 64, hipMemcpyDeviceToHost, stream));
+                WDX_HIP_TRY(hipStreamSynchronize(stream));
                 fprintf(stderr, "[wdx] handed to the exact kernel by the fast kernels, by reason (0 parameter gate / window, 1 NaN or negative, "
                                 "2 sums not provably exact, 3 plateau or peak-list capacity, 4 neighbourhood, 5 kept-list capacity, 6 tie at the "
                                 "top-E cut, 7 doubt without a retry list, 8 fewer peaks than events with accept_less_cpts):");
