@@ -1714,8 +1714,26 @@ static int fast_combo(const wdx_seg_params &p) {
     if (p.running_stat_width == 36 && p.min_obs_per_base <= 17) return 6;
     if (p.running_stat_width == 12 && p.min_obs_per_base <= 17) return 7;   // (9 < d <= 17: the NBT = 2 form of the width)
     if (p.running_stat_width == 18 && p.min_obs_per_base <= 17) return 8;
+    // 9 .. 18 (round 6): every other EVEN width up to 34, d <= 17 -- widths that are not multiples of six, on the fast kernels' EXACT-scores
+    // pass (the partner window's statistics come from another slot of a lane one further); no approximate keys, no retry launch
+    if (p.min_obs_per_base <= 17) {
+        switch (p.running_stat_width) {
+            case 8: return 9;
+            case 10: return 10;
+            case 14: return 11;
+            case 16: return 12;
+            case 20: return 13;
+            case 22: return 14;
+            case 26: return 15;
+            case 28: return 16;
+            case 32: return 17;
+            case 34: return 18;
+            default: break;
+        }
+    }
     return 0;
 }
+static bool fast_combo_exact_only(int combo) { return combo >= 9; }
 
 int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32_t *d_row_len,
                        int64_t stride, int64_t max_len, int64_t n_reads, const int32_t *d_a_start,
@@ -1805,8 +1823,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // leave headroom within the LDS budget of the instantiation's occupancy; overflows move up the chain.
         const int64_t chain_min = knobs.fast_chain_min > 0 ? knobs.fast_chain_min : 2048;
         const bool large_batch = n_reads >= chain_min;
-        const bool approx = large_batch && !knobs.fast_exact_scores;
         const int combo = fast_combo(p);
+        const bool approx = large_batch && !knobs.fast_exact_scores && !fast_combo_exact_only(combo);
         const int nbt = combo >= 3 ? 2 : 1;
         int capF = cap <= 4096 ? 4096 : (large_batch ? 5120 : 6144);
         if (knobs.fast_main_cap == 5120 || knobs.fast_main_cap == 6144) capF = knobs.fast_main_cap;  // experiments
@@ -1878,7 +1896,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             kern_ls = fingerprint_fast_list_kernel<kNptHuge, FWx, 2>;
             kern_st = fingerprint_fast_stream_kernel<FWx, 2>;
             slot = 2;
-            if constexpr (FWx >= 12) {   // (the widths whose EXT main kernel runs the filtered 512-entry list)
+            if constexpr (FWx >= 12 && FWx % 6 == 0) {   // (the widths whose EXT main kernel runs the filtered 512-entry list)
                 kern_a = fingerprint_fast_kernel<kNptLarge, false, FWx, 2, true, true>;
                 kern_b = fingerprint_split_tail_kernel<FWx, 2>;
             }
@@ -1907,6 +1925,26 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             wide_set(std::integral_constant<int, 12>{});
         } else if (combo == 8) {
             wide_set(std::integral_constant<int, 18>{});
+        } else if (combo == 9) {
+            wide_set(std::integral_constant<int, 8>{});
+        } else if (combo == 10) {
+            wide_set(std::integral_constant<int, 10>{});
+        } else if (combo == 11) {
+            wide_set(std::integral_constant<int, 14>{});
+        } else if (combo == 12) {
+            wide_set(std::integral_constant<int, 16>{});
+        } else if (combo == 13) {
+            wide_set(std::integral_constant<int, 20>{});
+        } else if (combo == 14) {
+            wide_set(std::integral_constant<int, 22>{});
+        } else if (combo == 15) {
+            wide_set(std::integral_constant<int, 26>{});
+        } else if (combo == 16) {
+            wide_set(std::integral_constant<int, 28>{});
+        } else if (combo == 17) {
+            wide_set(std::integral_constant<int, 32>{});
+        } else if (combo == 18) {
+            wide_set(std::integral_constant<int, 34>{});
         } else if (capF == 4096) {
             kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptSmall, true, kFW, 1, true> : fingerprint_fast_kernel<kNptSmall, false, kFW, 1, true>)
                        : (d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>);
@@ -1921,7 +1959,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
             slot = 2;
         }
-        static LdsAttr attr_fast[8][12];
+        static LdsAttr attr_fast[24][12];
         if (int rc = attr_fast[combo - 1][(ext ? 6 : 0) + (d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
@@ -1964,7 +2002,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool split = kern_a && ext && approx && filt && capP == 512 && chain && !d_prof && !rf && !knobs.no_split;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         if (split) {
-            static LdsAttr attr_split[8];
+            static LdsAttr attr_split[24];
             if (int rc = attr_split[combo - 1].ensure(kern_a, flds)) return rc;
             F.split_ws = reinterpret_cast<unsigned char *>(d_ws) + split_ws_offset(n_reads);
             const int64_t slice = launch_slice_limit(kSplitSlice);
@@ -2003,7 +2041,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // where the peak list will be, so its list region must hold 8448 bytes -- 768 entries, not 512)
         const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 768 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
-        static LdsAttr attr_l1[8], attr_huge[8];
+        static LdsAttr attr_l1[24], attr_huge[24];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
         if (with_big0 || with_big1 || with_stream || (approx && chain))
@@ -2018,7 +2056,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             if (split && kern_a1 && capP1f == 512) {
                 // the same pair over the list's entries (slot = workgroup of the slice; most of the grid lies past the list's end
                 // and leaves at once, in both kernels)
-                static LdsAttr attr_split1[8];
+                static LdsAttr attr_split1[24];
                 if (int rc = attr_split1[combo - 1].ensure(kern_a1, flds1f)) return rc;
                 F1.split_ws = F.split_ws;
                 const int64_t slice = launch_slice_limit(kSplitSlice);
@@ -2061,7 +2099,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int capPs = filt ? (scap == 8192 ? 1024 : (scap == 12288 ? 1280 : 1536))   // (the list from kPeakTauLo up)
                                    : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
-            static LdsAttr attr_cb, attr_st[8];
+            static LdsAttr attr_cb, attr_st[24];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
             // (WDX_OPT_MAX_LAUNCH_SLICE, the tests' switch for the multi-launch paths, also selects the bounded grids)
