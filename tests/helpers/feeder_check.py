@@ -59,6 +59,31 @@ def work(widx):
     return os.getpid(), out, errs
 
 
+def loop_until_stopped(widx):
+    """ADVICE r5 (shutdown race): a worker that keeps calling while the parent stops the feeder.  Every call must either
+    return a CORRECT result (a minibatch that was in flight when the stop came is finished and handed over -- never the
+    previous occupant's numbers) or raise WdxNoDevice; nothing may hang."""
+    spec = synth.SynthSpec(n_barcodes=6)
+    batches = []
+    for rep in range(3):
+        mb, a_s, a_e, _ = synth.generate_minibatch(spec, 50_000 + 1000 * widx + 100 * rep, 48 + 16 * rep, 7000)
+        fpt, dwell, stats, status = orc.fingerprint_batch(mb, a_s, a_e, orc.SegParams(barcode_num_events=110))
+        batches.append((mb, a_s, a_e, status, fpt))
+    served, told, wrong = 0, 0, 0
+    for it in range(100000):
+        mb, a_s, a_e, status, fpt = batches[it % 3]
+        try:
+            fb = FEEDER.fingerprint_batch(mb, a_s, a_e)
+        except _lib.WdxNoDevice:
+            told += 1
+            break
+        ok = status == 0
+        if not (np.array_equal(fb.status, status) and np.array_equal(fb.fpt[ok].view(np.uint64), fpt[ok].view(np.uint64))):
+            wrong += 1
+        served += 1
+    return served, told, wrong
+
+
 def die_with_a_slot(_):
     """A worker that claims a ring slot (the test hook claims exactly like wdx_feeder_run does) and is killed before it
     gives it back -- an OOM kill, pool.terminate()."""
@@ -106,6 +131,17 @@ if __name__ == "__main__":
         told = list(ex.map(after_death, range(1)))[0]
     zombie = open(f"/proc/{FEEDER._proc.pid}/stat").read().rsplit(") ", 1)[1][0]
     FEEDER.close()
+    # a second feeder, stopped (close) while six workers hammer it: correct results or WdxNoDevice, nothing else, no hang
+    FEEDER = Feeder(REFS, 15, 0.1, sig_proc.SegParams(barcode_num_events=110), max_reads=256, stride=9000, n_slots=4)
+    with ProcessPoolExecutor(max_workers=6, mp_context=ctx) as ex:
+        futs = [ex.submit(loop_until_stopped, w) for w in range(6)]
+        t0 = time.monotonic()
+        while FEEDER.served() < 60 and time.monotonic() - t0 < 60:
+            time.sleep(0.002)
+        FEEDER.close()
+        stopped = [f.result(timeout=120) for f in futs]
     print(json.dumps({"pids": sorted({r[0] for r in res}), "ok": [r[1] for r in res] + [r[1] for r in again],
                       "errs": [r[2] for r in res], "parent": os.getpid(), "served": served, "reclaim": reclaim,
-                      "feeder_state_when_the_worker_was_told": zombie, "after_death": told}))
+                      "feeder_state_when_the_worker_was_told": zombie, "after_death": told,
+                      "stopped_while_busy": {"served": [s_[0] for s_ in stopped], "told": [s_[1] for s_ in stopped],
+                                             "wrong": [s_[2] for s_ in stopped]}}))

@@ -269,6 +269,9 @@ def test_feeder_serves_forked_workers_and_reports_its_own_death():
     assert rec["feeder_state_when_the_worker_was_told"] == "Z", rec
     # a worker SIGKILLed with a slot in its hands: the ring has all its slots again
     assert rec["reclaim"]["reclaimed"] == 1 and rec["reclaim"]["free_slots"] == rec["reclaim"]["n_slots"], rec
+    # stopped while six workers were calling: every call returned correct numbers or WdxNoDevice, every worker was told
+    sw = rec["stopped_while_busy"]
+    assert sum(sw["wrong"]) == 0 and all(t == 1 for t in sw["told"]) and sum(sw["served"]) >= 60, sw
 
 
 def test_feeder_returns_the_reference_workers_whole_minibatch_on_a_real_model():
