@@ -1033,12 +1033,15 @@ def run_rank(args):
     # tools/collect_traffic.py on the same workload); null when not collected for this size
     # NOT measured by this run: PMC counters need rocprofv3 around the process, so these two figures are read from the
     # committed passes of the same workload and carry their source (file, round) in the line
-    traffic = traffic_src = None
+    traffic = traffic_src = traffic_parts = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             tj = json.load(fh)
         if tj.get("kernel") == dom and tj.get("reads_per_step") == n_reads:
             traffic = tj.get("hbm_bytes_per_step") / launches_per_step
+            traffic_parts = {"fetched_per_launch": tj.get("fetch_bytes_per_launch_corrected"), "written_per_launch": tj.get("write_bytes_per_launch"),
+                             "note": "the tile kernel reads each sample once (fetched = 1.02 x its algorithmic bytes); what it writes are the "
+                                     "exported peak lists (<= 4.6 KB per read) that the tail kernel reads back"}
             traffic_src = {"file": "profiles/traffic.json", "round": tj.get("round"), "collected_by": "tools/collect_traffic.py "
                            "(separate rocprofv3 --pmc passes of this command; not measured by this run)"}
     except (OSError, ValueError, TypeError):
@@ -1098,6 +1101,7 @@ def run_rank(args):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_parts": traffic_parts,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches": dom_n,
