@@ -494,6 +494,8 @@ int wdx_kernel_time_reset(wdx_ctx *ctx);
  * stamps at the phase boundaries P0..P7, 10 = suppression iterations, 11 = adapter samples,
  * 12 = score positions / peaks).  fast_path selects the 256-thread fast kernel (+ slow-path list;
  * slot 15 of read 0 then holds the number of reads it declined) or the one-kernel exact path.
+ * fast_path == 2: the split pair of the RNA004 main kernel (tile kernel: slots 0, 3, 4 = start, samples clipped in LDS, tile pass
+ * done, 5 = export done; tail kernel: 6 entries loaded, 7 boundaries written, 8 event means + mean / sd, 9 end; 12 = exported peaks).
  * stop_phase k > 0 makes the fast kernel return after phase k (ablation timing; results are garbage).
  * Outputs other than d_status are discarded.  Never on the product path. */
 int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,

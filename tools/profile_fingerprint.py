@@ -30,6 +30,22 @@ torch.cuda.synchronize()
 p = prof.cpu().numpy()
 ok = status.cpu().numpy() == 0
 declined = int(p[0, 15]) if fast else 0
+if fast == 2:
+    # the split pair (round 6): tile kernel slots 0 / 3 / 4 / 5, tail kernel slots 6 .. 9 (two kernels: two clocks' worth of
+    # differences, never across the pair)
+    q = p[(p[:, 9] != 0) & (p[:, 5] != 0)]
+    print(f"split pair, {q.shape[0]} of {n} reads finished by it (the others: longer windows, hand-overs)")
+    tile_tot = q[:, 5] - q[:, 0]
+    tail_tot = q[:, 9] - q[:, 6]
+    rows = [("tile kernel: P0 load + clip", q[:, 3] - q[:, 0], tile_tot), ("tile kernel: P2+P3a t-score tiles + maxima", q[:, 4] - q[:, 3], tile_tot),
+            ("tile kernel: export (pick, half-chunk prefixes, P at the peaks)", q[:, 5] - q[:, 4], tile_tot),
+            ("tail kernel: window, suppression, top-E, boundaries", q[:, 7] - q[:, 6], tail_tot),
+            ("tail kernel: event means, mean / sd", q[:, 8] - q[:, 7], tail_tot), ("tail kernel: normalise, output", q[:, 9] - q[:, 8], tail_tot)]
+    for name, dd, tot in rows:
+        print(f"  {name:64s} median {np.median(dd):8.0f}  mean {dd.mean():9.0f}  share of its kernel {dd.sum() / tot.sum() * 100:5.1f}%")
+    print(f"  tile kernel: a workgroup's cycles median {np.median(tile_tot):.0f} mean {tile_tot.mean():.0f} (one-piece kernel: ~42 500); "
+          f"tail kernel: a wave's cycles median {np.median(tail_tot):.0f} mean {tail_tot.mean():.0f}; exported peaks median {np.median(q[:, 12]):.0f} max {q[:, 12].max():.0f}")
+    sys.exit(0)
 if fast:
     dec = p[p[:, 9] == 0]
     print("handed on by the main kernel (0 window beyond its capacity / parameter gate, 1 NaN, 2 sums not provably exact, "

@@ -640,7 +640,8 @@ int wdx_fingerprint_profile_dev(wdx_ctx *ctx, const float *d_sig, const int64_t 
     if ((rc = ctx->fp_ws.ensure((size_t)fingerprint_workspace_bytes(n_reads)))) return rc;
     rc = launch_fingerprint(d_sig, d_row_off, nullptr, stride, max_len, n_reads, d_a_start, d_a_end,
                             nullptr, *p, nullptr, nullptr, nullptr, d_status, (hipStream_t)stream,
-                            fast_path ? ctx->fp_ws.p : nullptr, ctx->knobs, nullptr, d_prof, prof_reads, stop_phase);
+                            fast_path ? ctx->fp_ws.p : nullptr, ctx->knobs, nullptr, d_prof, prof_reads,
+                            fast_path == 2 ? -2 : stop_phase);   // (-2: the split pair's diagnostic build)
     if (rc == WDX_SUCCESS && fast_path && prof_reads > 0 && stop_phase == 0) {
         // slot 15 of read 0 <- number of reads the fast kernel handed to the slow path
         WDX_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

@@ -1999,11 +1999,14 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // slices of kSplitSlice reads, whose lists live in the workspace behind the read lists.  Not for the diagnostic builds
         // (the one-piece kernel serves those).
         // (not the refinement branch: measured 2.36 against 2.15 ms per 32 768 tRNA-like reads with the one-piece kernel)
-        const bool split = kern_a && ext && approx && filt && capP == 512 && chain && !d_prof && !rf && !knobs.no_split;
+        // (stop_phase == -2: the diagnostic build of the RNA004 pair, wdx_fingerprint_profile_dev's fast_path = 2)
+        const bool prof_split = d_prof && stop_phase == -2 && combo == 1 && capF == 5120;
+        if (prof_split) kern_a = fingerprint_fast_kernel<kNptMid, true, kFW, 1, true, true>;
+        const bool split = kern_a && ext && approx && filt && capP == 512 && chain && (!d_prof || prof_split) && !rf && !knobs.no_split;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         if (split) {
-            static LdsAttr attr_split[24];
-            if (int rc = attr_split[combo - 1].ensure(kern_a, flds)) return rc;
+            static LdsAttr attr_split[24], attr_split_prof;
+            if (int rc = (prof_split ? attr_split_prof : attr_split[combo - 1]).ensure(kern_a, flds)) return rc;
             F.split_ws = reinterpret_cast<unsigned char *>(d_ws) + split_ws_offset(n_reads);
             const int64_t slice = launch_slice_limit(kSplitSlice);
             for (int64_t base = 0; base < n_reads; base += slice) {
