@@ -1925,26 +1925,18 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             wide_set(std::integral_constant<int, 12>{});
         } else if (combo == 8) {
             wide_set(std::integral_constant<int, 18>{});
-        } else if (combo == 9) {
-            wide_set(std::integral_constant<int, 8>{});
-        } else if (combo == 10) {
-            wide_set(std::integral_constant<int, 10>{});
-        } else if (combo == 11) {
-            wide_set(std::integral_constant<int, 14>{});
-        } else if (combo == 12) {
-            wide_set(std::integral_constant<int, 16>{});
-        } else if (combo == 13) {
-            wide_set(std::integral_constant<int, 20>{});
-        } else if (combo == 14) {
-            wide_set(std::integral_constant<int, 22>{});
-        } else if (combo == 15) {
-            wide_set(std::integral_constant<int, 26>{});
-        } else if (combo == 16) {
-            wide_set(std::integral_constant<int, 28>{});
-        } else if (combo == 17) {
-            wide_set(std::integral_constant<int, 32>{});
-        } else if (combo == 18) {
-            wide_set(std::integral_constant<int, 34>{});
+        } else if (combo >= 9) {
+            // the exact-scores-only widths: instantiated in wdx_fingerprint_w1.hip / _w2.hip
+            FastKernelSet ks{};
+            if (!exact_only_kernels_a(p.running_stat_width, ext, ks) && !exact_only_kernels_b(p.running_stat_width, ext, ks)) {
+                set_error("no fast kernels for running_stat_width %d", (int)p.running_stat_width);
+                return WDX_ERR_INVALID;
+            }
+            kern = ks.main;
+            kern_l1 = ks.l1;
+            kern_ls = ks.ls;
+            kern_st = ks.st;
+            slot = 2;
         } else if (capF == 4096) {
             kern = ext ? (d_prof ? fingerprint_fast_kernel<kNptSmall, true, kFW, 1, true> : fingerprint_fast_kernel<kNptSmall, false, kFW, 1, true>)
                        : (d_prof ? fingerprint_fast_kernel<kNptSmall, true> : fingerprint_fast_kernel<kNptSmall, false>);
