@@ -221,7 +221,8 @@ int wdx_fingerprint_refine_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *
  * d_dist: (n_reads,nY) float32; d_call: int32[n_reads] = argmin column or -1 for failed reads;
  * d_counts (nullable): int64[nY+1], INCREMENTED by the per-column call histogram, slot nY =
  * failed reads.  d_fpt/d_dwell/d_stats are optional as above.  d_work: DEVICE scratch of at
- * least wdx_demux_workspace_bytes(n_reads, K) bytes. */
+ * least wdx_demux_workspace_bytes(n_reads, K) bytes (fingerprints, the chain's hand-over lists and clip records -- 40 bytes per
+ * read -- and the split main kernel's peak lists for one launch slice: 4 624 bytes per read of min(n_reads, 524 288)). */
 int64_t wdx_demux_workspace_bytes(int64_t n_reads, int32_t barcode_num_events);
 int wdx_demux_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off,
                   const int32_t *d_row_len, int64_t stride, int64_t max_len, int64_t n_reads,
