@@ -428,10 +428,10 @@ def test_fast_kernels_of_the_other_shipped_triples(triple):
 @pytest.mark.parametrize("w", range(6, 37))
 def test_every_window_width_and_reach_against_the_oracle(w):
     """running_stat_width 6 .. 36 x min_obs_per_base 2 .. 17 (any value `--export segmentation.…` can set,
-    config/sig_proc.py:16-70): multiples of six run on the fast kernels' approximate keys (reach <= 17), every other EVEN
-    width on their exact-scores pass (round 6: the partner window's statistics come from slot (rr + W) % 6 of the lane
-    (rr + W) / 6 further), odd widths on the exact general kernel -- the same fingerprints as the oracle every way,
-    through the launch chain of large batches."""
+    config/sig_proc.py:16-70): multiples of six run on the fast kernels' approximate keys (reach <= 17), every other
+    width -- odd ones included -- on their exact-scores pass (round 6: the partner window's statistics come from slot
+    (rr + W) % 6 of the lane (rr + W) / 6 further) -- the same fingerprints as the oracle every way, through the launch
+    chain of large batches."""
     spec = synth.SynthSpec(n_barcodes=10)
     n = 96
     mb, a_s, a_e, _ = synth.generate_minibatch(spec, 4242 + w, n, 9000)

@@ -1714,23 +1714,11 @@ static int fast_combo(const wdx_seg_params &p) {
     if (p.running_stat_width == 36 && p.min_obs_per_base <= 17) return 6;
     if (p.running_stat_width == 12 && p.min_obs_per_base <= 17) return 7;   // (9 < d <= 17: the NBT = 2 form of the width)
     if (p.running_stat_width == 18 && p.min_obs_per_base <= 17) return 8;
-    // 9 .. 18 (round 6): every other EVEN width up to 34, d <= 17 -- widths that are not multiples of six, on the fast kernels' EXACT-scores
-    // pass (the partner window's statistics come from another slot of a lane one further); no approximate keys, no retry launch
-    if (p.min_obs_per_base <= 17) {
-        switch (p.running_stat_width) {
-            case 8: return 9;
-            case 10: return 10;
-            case 14: return 11;
-            case 16: return 12;
-            case 20: return 13;
-            case 22: return 14;
-            case 26: return 15;
-            case 28: return 16;
-            case 32: return 17;
-            case 34: return 18;
-            default: break;
-        }
-    }
+    // 9 .. 37 (round 6): every other width from 7 to 35, d <= 17 -- widths that are not multiples of six, on the fast kernels'
+    // EXACT-scores pass (the partner window's statistics come from another slot of a lane one further); no approximate keys,
+    // no retry launch.  combo = 9 + (W - 7)
+    if (p.min_obs_per_base <= 17 && p.running_stat_width >= 7 && p.running_stat_width <= 35 && p.running_stat_width % 6 != 0)
+        return 9 + (p.running_stat_width - 7);
     return 0;
 }
 static bool fast_combo_exact_only(int combo) { return combo >= 9; }
@@ -1858,7 +1846,9 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool with_big0 = chain && capF == 5120;            // windows of 5121..6144 samples, peak-list overflows
         // windows beyond 6144 samples, up to WDX_MAX_ADAPTER_SAMPLES: the streaming fast kernel (at 8 000 samples it is
         // faster than the striding 8192-sample list kernel, which then only serves list overflows and exact-score retries)
-        const bool with_stream = chain && ext && capF >= 5120 && max_len > 6144;
+        // (odd widths are instantiated without the streaming form: their windows beyond 8192 samples take the exact kernel)
+        const bool has_stream = !(fast_combo_exact_only(combo) && (p.running_stat_width & 1));
+        const bool with_stream = chain && ext && capF >= 5120 && max_len > 6144 && has_stream;
         const bool with_big1 = chain && capF >= 5120 && cap > 6144 && !with_stream;  // windows of 6145..8192 samples
         A.exact_scores = approx ? 0 : 1;
         A.peak_filter = knobs.no_peak_filter ? 0 : 1;   // (only the approximate-keys launches look at it)
@@ -1928,7 +1918,8 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         } else if (combo >= 9) {
             // the exact-scores-only widths: instantiated in wdx_fingerprint_w1.hip / _w2.hip
             FastKernelSet ks{};
-            if (!exact_only_kernels_a(p.running_stat_width, ext, ks) && !exact_only_kernels_b(p.running_stat_width, ext, ks)) {
+            if (!exact_only_kernels_a(p.running_stat_width, ext, ks) && !exact_only_kernels_b(p.running_stat_width, ext, ks) &&
+                !exact_only_kernels_c(p.running_stat_width, ext, ks) && !exact_only_kernels_d(p.running_stat_width, ext, ks)) {
                 set_error("no fast kernels for running_stat_width %d", (int)p.running_stat_width);
                 return WDX_ERR_INVALID;
             }
@@ -1951,7 +1942,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
                        : (d_prof ? fingerprint_fast_kernel<kNptLarge, true> : fingerprint_fast_kernel<kNptLarge, false>);
             slot = 2;
         }
-        static LdsAttr attr_fast[24][12];
+        static LdsAttr attr_fast[40][12];
         if (int rc = attr_fast[combo - 1][(ext ? 6 : 0) + (d_prof ? 3 : 0) + slot].ensure(kern, flds)) return rc;
         if (knobs.debug_occ) {
             int nb = 0;
@@ -1997,7 +1988,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         const bool split = kern_a && ext && approx && filt && capP == 512 && chain && (!d_prof || prof_split) && !rf && !knobs.no_split;
         if (main_ev && main_ev->first) (void)hipEventRecord(main_ev->first, stream);
         if (split) {
-            static LdsAttr attr_split[24], attr_split_prof;
+            static LdsAttr attr_split[40], attr_split_prof;
             if (int rc = (prof_split ? attr_split_prof : attr_split[combo - 1]).ensure(kern_a, flds)) return rc;
             F.split_ws = reinterpret_cast<unsigned char *>(d_ws) + split_ws_offset(n_reads);
             const int64_t slice = launch_slice_limit(kSplitSlice);
@@ -2036,7 +2027,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
         // where the peak list will be, so its list region must hold 8448 bytes -- 768 entries, not 512)
         const int capP1f = filt && nbt == 1 ? 512 : capP1, capP2f = filt && nbt == 1 ? 768 : capP2;
         const size_t flds1f = fast_lds_bytes(capF1, capP1f, nbt), flds2f = fast_lds_bytes(capF2, capP2f, nbt);
-        static LdsAttr attr_l1[24], attr_huge[24];
+        static LdsAttr attr_l1[40], attr_huge[40];
         if (with_big0 || (approx && chain))
             if (int rc = attr_l1[combo - 1].ensure(kern_l1, flds1)) return rc;
         if (with_big0 || with_big1 || with_stream || (approx && chain))
@@ -2051,7 +2042,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             if (split && kern_a1 && capP1f == 512) {
                 // the same pair over the list's entries (slot = workgroup of the slice; most of the grid lies past the list's end
                 // and leaves at once, in both kernels)
-                static LdsAttr attr_split1[24];
+                static LdsAttr attr_split1[40];
                 if (int rc = attr_split1[combo - 1].ensure(kern_a1, flds1f)) return rc;
                 F1.split_ws = F.split_ws;
                 const int64_t slice = launch_slice_limit(kSplitSlice);
@@ -2094,7 +2085,7 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
             const int capPs = filt ? (scap == 8192 ? 1024 : (scap == 12288 ? 1280 : 1536))   // (the list from kPeakTauLo up)
                                    : (scap == 8192 ? 1700 : (scap == 12288 ? 2520 : 3400));
             const size_t lds_cb = clip_block_lds_bytes(scap), lds_st = fast_stream_lds_bytes(capPs, nbt);
-            static LdsAttr attr_cb, attr_st[24];
+            static LdsAttr attr_cb, attr_st[40];
             if (int rc = attr_cb.ensure(clip_bounds_block_kernel, lds_cb)) return rc;
             if (int rc = attr_st[combo - 1].ensure(kern_st, lds_st)) return rc;
             // (WDX_OPT_MAX_LAUNCH_SLICE, the tests' switch for the multi-launch paths, also selects the bounded grids)
