@@ -118,6 +118,10 @@ int wdx_ctx_stream(wdx_ctx *ctx, void **stream);
 #define WDX_OPT_NO_WAVE_CLIP_LONG 13    /* windows beyond 6144 samples: clip bounds by the workgroup kernel alone (A/B, tests) */
 #define WDX_OPT_NO_CLIP_REUSE 14        /* exact kernel behind the launch chain: recompute the clip bounds (A/B, tests) */
 #define WDX_OPT_NO_SPLIT_TAIL 15        /* main fast fingerprint kernel in one piece: no tile kernel + tail kernel split (A/B, tests) */
+#define WDX_OPT_DTW_UNFUSED 16          /* DTW cells: 0 (default) one v_fma_f64 per cell, pairs whose float32 could differ from the
+                                         * reference's are run again on its six operations (wdx_dtw.hip: dtw_unsettled) | 1 the six
+                                         * operations only (A/B) | 2 fused and every pair run again (tests) | 3 fused, never run again
+                                         * (diagnostic: NOT the reference's results) */
 int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value);
 
 /* ---- seam 1: batched DTW  (replaces parallel_distances.py:48-67 `distance_matrix_to`,

@@ -4,7 +4,9 @@ golden fixtures.  Needs a real MI355X: run with `pytest -m gpu`.
 Bar: integer outputs (status, change-point-derived dwell, argmin) bit-exact; float64 fingerprints
 and stats bit-exact (same operation order, no FMA); float32 DTW distances bit-exact against the
 oracle (tolerance the north star allows: 1e-5 relative -- asserted separately so a rounding
-difference in sqrt would be reported as such, not hidden).
+difference in sqrt would be reported as such, not hidden).  The DTW kernels run fused cells first and
+settle every pair whose float32 could differ on the reference's operations (wdx_dtw.hip: dtw_unsettled;
+test_dtw_fused_cells_settle_to_the_reference_bits).
 """
 import os
 
@@ -135,6 +137,63 @@ def test_dtw_nan_inf_and_ties():
     _check_dist(got, ref)
     assert np.array_equal(am, np.argmin(ref, axis=1))
     assert got[10, 2] == 0.0 and got[10, 7] == 0.0 and am[10] == 2
+
+
+@contextlib.contextmanager
+def _dtw_mode(mode):
+    """WDX_OPT_DTW_UNFUSED: 0 product | 1 the reference's six operations only | 2 fused + every pair settled | 3 fused, never settled"""
+    ctx = _lib.default_context()
+    ctx.set_option(_lib.OPT_DTW_UNFUSED, mode)
+    try:
+        yield
+    finally:
+        ctx.set_option(_lib.OPT_DTW_UNFUSED, 0)
+
+
+def test_dtw_fused_cells_settle_to_the_reference_bits():
+    """The DTW kernels compute a cell as one v_fma_f64 (five float64 operations, not six) and run a pair again on the
+    reference's operations whenever its float32 could differ (wdx_dtw.hip: dtw_unsettled).  Fixture g10: the 11 pairs of
+    4.6e10 searched on an MI355X whose fused float32 DOES differ (tools/find_fused_hard_pairs.py; inputs only, the
+    expected distances are the oracle's, computed here).  On them, and on everything around them: the product mode, the
+    six-operations mode and the settle-everything mode return the oracle's bits; the never-settle diagnostic does not
+    (the positive control: these pairs are what the check exists for).  Scaled inputs reach the underflow / overflow
+    guards of the check."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_dtw_fused_hard_pairs.npz"))
+    w, p = int(g["window"]), float(g["penalty"])
+    for L, npad in ((25, 3000), (110, 20000)):   # (enough pairs for the band / short kernels: > 16 384)
+        x, y = g[f"x{L}"], g[f"y{L}"]
+        m = x.shape[0]
+        assert m >= 1
+        rng = np.random.default_rng(L + 77)
+        X = rng.normal(size=(npad, L))
+        at = rng.choice(npad, m, replace=False)
+        X[at] = x
+        ref = orc.dtw_matrix(X, y, w, p)
+        for mode in (0, 1, 2):
+            with _dtw_mode(mode):
+                got, am = pdist.nearest_reference(X, y, w, p)
+            _check_dist(got, ref)
+            assert np.array_equal(am, np.argmin(ref, axis=1))
+        with _dtw_mode(3):
+            raw = pdist.distance_matrix_to(X, y, window=w, penalty=p, n_jobs=1)
+        assert all(raw[at[i], i] != ref[at[i], i] for i in range(m)), "the fixture's pairs no longer tell fused from unfused cells"
+        assert np.count_nonzero(raw != ref) == m
+        assert np.allclose(raw, ref, rtol=2e-7, atol=0.0)   # (one float32 ulp)
+    # the guards: sums below 1e-280 / above 1e280 are settled on the reference's operations (underflow makes errors absolute)
+    rng = np.random.default_rng(2)
+    X, Y = rng.normal(size=(2000, 110)), rng.normal(size=(10, 110))
+    for scale in (1e-160, 1e-150, 1e-139, 1e139, 1e150, 1e160):
+        ref = orc.dtw_matrix(X * scale, Y * scale, w, p)
+        for mode in (0, 2):
+            with _dtw_mode(mode):
+                _check_dist(pdist.distance_matrix_to(X * scale, Y * scale, window=w, penalty=p, n_jobs=1), ref)
+    # windows served by the masked band kernels and short rows, in the settle-everything mode
+    for wv, Lv in ((3, 40), (8, 57), (12, 110), (16, 31), (20, 110), (32, 64)):
+        X, Y = rng.normal(size=(700, Lv)), rng.normal(size=(30, Lv))
+        ref = orc.dtw_matrix(X, Y, wv, 0.1)
+        for mode in (0, 2):
+            with _dtw_mode(mode):
+                _check_dist(pdist.distance_matrix_to(X, Y, window=wv, penalty=0.1, n_jobs=1), ref)
 
 
 def test_dtw_symmetry_and_block_api():

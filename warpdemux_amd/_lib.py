@@ -36,6 +36,7 @@ OPT_NO_PEAK_FILTER = 12
 OPT_NO_WAVE_CLIP_LONG = 13
 OPT_NO_CLIP_REUSE = 14
 OPT_NO_SPLIT_TAIL = 15
+OPT_DTW_UNFUSED = 16
 COMM_ID_BYTES = 128
 ABI_VERSION = 4
 

@@ -447,6 +447,7 @@ int wdx_ctx_set_option(wdx_ctx *ctx, int32_t option, int64_t value) {
         case WDX_OPT_NO_WAVE_CLIP_LONG: ctx->knobs.no_wave_clip_long = value != 0; break;
         case WDX_OPT_NO_CLIP_REUSE: ctx->knobs.no_clip_reuse = value != 0; break;
         case WDX_OPT_NO_SPLIT_TAIL: ctx->knobs.no_split = value != 0; break;
+        case WDX_OPT_DTW_UNFUSED: ctx->knobs.dtw_unfused = (value >= 0 && value <= 3) ? (int)value : 0; break;
         case WDX_OPT_MAX_LAUNCH_SLICE: ctx->knobs.max_launch_slice = value > 0 ? value : 0; break;
         default:
             set_error("unknown option %d", (int)option);
@@ -1505,7 +1506,7 @@ int wdx_demux_svm_dev(wdx_ctx *ctx, const float *d_sig, const int64_t *d_row_off
             if ((rc = launch_dtw_svm_partial(fpt, n_reads, (const double *)ctx->svm_refs.p, R.Lpad, R.halo,
                                              (const uint8_t *)ctx->svm_refs.p + rb, R.L, R.window, R.penalty, ctx->svm_coefT,
                                              ctx->svm_chunk_ref0, ctx->svm_chunk_slot, ctx->svm_chunks, k - 1, M.pwr, M.ngamma,
-                                             (double *)ctx->out0.p, s)))
+                                             (double *)ctx->out0.p, s, ctx->knobs.dtw_unfused)))
                 return rc;
         }
         {

@@ -40,6 +40,7 @@ struct Knobs {
     bool no_peak_filter = false;     // WDX_OPT_NO_PEAK_FILTER: fast kernels append every local maximum (no threshold filter)
     int64_t max_launch_slice = 0;    // WDX_OPT_MAX_LAUNCH_SLICE: upper bound of one launch slice of the fingerprint chain (0 = built-in)
     bool no_split = false;           // WDX_OPT_NO_SPLIT_TAIL: the main fast kernel in one piece (A/B, tests)
+    int dtw_unfused = 0;             // WDX_OPT_DTW_UNFUSED: 0 fused cells + settle | 1 six operations only | 2 / 3 tests, diagnostics
 };
 
 // A launch over more workgroups than grid.x admits is cut into slices (block_base != 0 from the second on).  The built-in
@@ -99,7 +100,7 @@ int64_t dtw_scratch_bytes(int64_t L, int window);
 int launch_dtw_svm_partial(const double *X, int64_t nA, const double *Ypad_sv, int64_t Lpad, int halo, const uint8_t *y_nan_sv,
                            int64_t L, int window, double penalty, const double *coefT, const int32_t *chunk_ref0,
                            const int32_t *chunk_slot, int n_chunks, int km1, int pwr, float ngamma, double *P,
-                           hipStream_t stream);
+                           hipStream_t stream, int unfused);
 int launch_gather_rows(const double *src, const uint8_t *sflag, const int32_t *d_idx, int64_t n, int64_t ld, double *dst,
                        uint8_t *dflag, hipStream_t stream);
 // anti-diagonal wavefront kernel for small problems (latency path)

@@ -33,7 +33,15 @@ __device__ __forceinline__ double min_f64(double a, double b) {
     return r;
 }
 
-template <int W, bool MASKED>
+// FMA: the cell as ONE v_fma_f64, (x - y)^2 + t with a single rounding -- five float64 operations per cell instead of
+// six.  Not the reference's bits cell by cell: see dtw_unsettled() for how the kernels return the reference's float32.
+template <bool FMA>
+__device__ __forceinline__ double dtw_cell(double d, double t) {
+    if constexpr (FMA) return __builtin_fma(d, d, t);
+    else return d * d + t;
+}
+
+template <int W, bool MASKED, bool FMA = false>
 __device__ __forceinline__ void dtw_row(double (&r)[2 * W - 1], double x,
                                         const double *__restrict__ yi, double p2, int jbase,
                                         int jlo, int jhi) {
@@ -41,12 +49,11 @@ __device__ __forceinline__ void dtw_row(double (&r)[2 * W - 1], double x,
     double left = WDX_INF;
 #pragma unroll
     for (int c = 0; c < B; ++c) {
-        double d = x - yi[c];
-        d = d * d;
+        const double d = x - yi[c];
         double up = (c + 1 < B) ? r[c + 1] : WDX_INF;
         double t = (c == 0 ? up : min_f64(up, left)) + p2;  // left of the first band cell is +inf
         t = min_f64(t, r[c]);
-        double v = d + t;
+        double v = dtw_cell<FMA>(d, t);
         if (MASKED) {
             int j = jbase + c;
             v = (j < jlo || j > jhi) ? WDX_INF : v;
@@ -59,35 +66,61 @@ __device__ __forceinline__ void dtw_row(double (&r)[2 * W - 1], double x,
 // dtw_row with a compile-time range [CLO, CHI] of band cells that lie inside the matrix: the head and tail
 // rows of the band without masks, and without touching the cells outside (head: they stay +inf; tail:
 // they go stale but are never read again).
-template <int W, int CLO, int CHI>
+template <int W, int CLO, int CHI, bool FMA = false>
 __device__ __forceinline__ void dtw_row_ct(double (&r)[2 * W - 1], double x, const double *__restrict__ yi,
                                            double p2) {
     constexpr int B = 2 * W - 1;
     double left = WDX_INF;
 #pragma unroll
     for (int c = CLO; c <= CHI; ++c) {
-        double d = x - yi[c];
-        d = d * d;
+        const double d = x - yi[c];
         const double up = (c + 1 < B) ? r[c + 1 < B ? c + 1 : 0] : WDX_INF;
         double t = (c == CLO ? up : min_f64(up, left)) + p2;
         t = min_f64(t, r[c]);
-        const double v = d + t;
+        const double v = dtw_cell<FMA>(d, t);
         r[c] = v;
         left = v;
     }
 }
 // head rows i = 0 .. W-2 (band cells c >= W-1-i), tail rows i = L-W+1+t, t = 0 .. W-2 (c <= 2W-3-t)
-template <int W, int... Is>
+template <int W, bool FMA, int... Is>
 __device__ __forceinline__ void dtw_head_rows(double (&r)[2 * W - 1], const double *__restrict__ xp, int64_t ldA,
                                               const double *__restrict__ y, double p2,
                                               std::integer_sequence<int, Is...>) {
-    (dtw_row_ct<W, W - 1 - Is, 2 * W - 2>(r, xp[(int64_t)Is * ldA], y + Is, p2), ...);
+    (dtw_row_ct<W, W - 1 - Is, 2 * W - 2, FMA>(r, xp[(int64_t)Is * ldA], y + Is, p2), ...);
 }
-template <int W, int... Ts>
+template <int W, bool FMA, int... Ts>
 __device__ __forceinline__ void dtw_tail_rows(double (&r)[2 * W - 1], const double *__restrict__ xp, int64_t ldA,
                                               const double *__restrict__ y, double p2, int i0,
                                               std::integer_sequence<int, Ts...>) {
-    (dtw_row_ct<W, 0, 2 * W - 3 - Ts>(r, xp[(int64_t)(i0 + Ts) * ldA], y + i0 + Ts, p2), ...);
+    (dtw_row_ct<W, 0, 2 * W - 3 - Ts, FMA>(r, xp[(int64_t)(i0 + Ts) * ldA], y + i0 + Ts, p2), ...);
+}
+
+// The fused cell and the reference's float32 (dtw_band_kernel, dtw_short_kernel, dtw_short_svm_kernel).
+// Every kernel first runs the pair on fused cells (FMA = true).  With u = 2^-53: the reference's cell is
+// fl(fl(d^2) + t), the fused one fl(d^2 + t'), d the same number in both; all values are non-negative, min and the
+// rounding are monotone, so if the three predecessor cells agree within a relative e the sums min(..) + p2 agree within
+// e + 2u and the cells within e + 5u (first order) -- a cell's predecessors lie one step of i + j earlier, hence the final
+// cells agree within (2 L - 1) 5u (1 + o(1)), and their correctly rounded square roots within half of that + 2u.  The
+// kernels take delta = 32 (L + 1) u (more than three times that): when [res (1 - delta), res (1 + delta)] rounds to one
+// float32, the reference's distance is that float32 (float conversion is monotone).  Otherwise -- a float32 rounding
+// boundary inside the interval: about one pair in 10^5 at L = 110 -- or when the sum left [1e-280, 1e280] (underflow
+// makes errors absolute; zero is exact: a zero fused sum means every term on its path was below 2^-1074 in both forms),
+// the WAVE runs the pair again on the reference's six operations and the flagged lanes take that result.  Returns the
+// lanes to settle.
+__device__ __forceinline__ bool dtw_unsettled(double Dv, double res, float f, double delta) {
+    const bool same = (float)(res * (1.0 - delta)) == f && (float)(res * (1.0 + delta)) == f;
+    const bool mid = Dv == 0.0 || (Dv > 1e-280 && Dv < 1e280);
+    return !(same && mid);
+}
+__device__ __forceinline__ double dtw_delta(int L) { return 32.0 * (double)(L + 1) * 0x1p-53; }
+// WDX_OPT_DTW_UNFUSED (the kernels' `unfused` argument): 0 as above | 1 the reference's six operations only | 2 fused, and
+// every pair is run again (tests: the second pass and the selection) | 3 fused, never run again (diagnostic: how often the
+// fused float32 differs -- NOT the reference's results)
+__device__ __forceinline__ bool dtw_redo(int mode, bool unsettled) {
+    if (mode == 2) return true;
+    if (mode == 3) return false;
+    return __ballot(unsettled) != 0ull;
 }
 
 // np.argmin running update on float32 values (first minimum; first NaN wins outright)
@@ -131,7 +164,7 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
     const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
     const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
     const uint8_t *__restrict__ b_nan, int L, int w, double p2, float *__restrict__ out,
-    int64_t sA, int64_t sB, int32_t *__restrict__ argmin, int refs_per_block) {
+    int64_t sA, int64_t sB, int32_t *__restrict__ argmin, int refs_per_block, int unfused) {
     constexpr int B = 2 * W - 1;
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = a < nA;
@@ -141,81 +174,95 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
     if (ROWMAJOR) ldA = 1;
     const double *__restrict__ xp = ROWMAJOR ? AT + al * (int64_t)L : AT + al;
     const bool anan = a_nan ? (a_nan[al] != 0) : (ROWMAJOR ? row_has_nan(xp, L) : false);
+    const double delta = dtw_delta(L);
     ArgminAcc acc;
 
     for (int b = b0; b < b1; ++b) {
         const double *__restrict__ y = Bpad + (int64_t)b * Lpad + (halo - (W - 1));
-        double r[B];
+        // the pair's accumulated cost D[L][L] on fused (FMA) or on the reference's cells
+        auto pair_cost = [&](auto fma_t) -> double {
+            constexpr bool FMA = decltype(fma_t)::value;
+            double r[B];
 #pragma unroll
-        for (int c = 0; c < B; ++c) r[c] = WDX_INF;
-        r[W - 1] = 0.0;
-        double xn = xp[0];
-        int i = 0;
-        if (EXACT_W && L >= 2 * (W - 1)) {
-            // head and tail rows from templates (no masks, no cells outside the matrix); loads of x are
-            // independent of the recurrence and get hoisted by the compiler
-            dtw_head_rows<W>(r, xp, ldA, y, p2, std::make_integer_sequence<int, W - 1>{});
-            i = W - 1;
-            if (ROWMAJOR) {
-                constexpr int CH = 8;
-                const int body_end = L - W + 1;
-                if (i + CH <= body_end) {
-                    double xc[CH];
+            for (int c = 0; c < B; ++c) r[c] = WDX_INF;
+            r[W - 1] = 0.0;
+            double xn = xp[0];
+            int i = 0;
+            if (EXACT_W && L >= 2 * (W - 1)) {
+                // head and tail rows from templates (no masks, no cells outside the matrix); loads of x are
+                // independent of the recurrence and get hoisted by the compiler
+                dtw_head_rows<W, FMA>(r, xp, ldA, y, p2, std::make_integer_sequence<int, W - 1>{});
+                i = W - 1;
+                if (ROWMAJOR) {
+                    constexpr int CH = 8;
+                    const int body_end = L - W + 1;
+                    if (i + CH <= body_end) {
+                        double xc[CH];
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) xc[k] = xp[i + k];
-                    for (; i + CH <= body_end; i += CH) {
-                        double xq[CH];
-                        const bool more = i + 2 * CH <= body_end;  // wave-uniform
-                        if (more) {
+                        for (int k = 0; k < CH; ++k) xc[k] = xp[i + k];
+                        for (; i + CH <= body_end; i += CH) {
+                            double xq[CH];
+                            const bool more = i + 2 * CH <= body_end;  // wave-uniform
+                            if (more) {
 #pragma unroll
-                            for (int k = 0; k < CH; ++k) xq[k] = xp[i + CH + k];
-                        }
+                                for (int k = 0; k < CH; ++k) xq[k] = xp[i + CH + k];
+                            }
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) dtw_row<W, false>(r, xc[k], y + i + k, p2, 0, 0, 0);
-                        if (more) {
+                            for (int k = 0; k < CH; ++k) dtw_row<W, false, FMA>(r, xc[k], y + i + k, p2, 0, 0, 0);
+                            if (more) {
 #pragma unroll
-                            for (int k = 0; k < CH; ++k) xc[k] = xq[k];
+                                for (int k = 0; k < CH; ++k) xc[k] = xq[k];
+                            }
                         }
                     }
+                    if (i < body_end) xn = xp[i];
+                } else {
+                    xn = xp[(int64_t)(W - 1) * ldA];
                 }
-                if (i < body_end) xn = xp[i];
+                for (; i < L - W + 1; ++i) {
+                    const double x = xn;
+                    xn = xp[(int64_t)(i + 1) * ldA];  // i + 1 <= L - W + 1 < L
+                    dtw_row<W, false, FMA>(r, x, y + i, p2, 0, 0, 0);
+                }
+                dtw_tail_rows<W, FMA>(r, xp, ldA, y, p2, L - W + 1, std::make_integer_sequence<int, W - 1>{});
+            } else if (EXACT_W) {
+                const int head_end = min(W - 1, L);          // rows whose band leaves [0, L)
+                const int body_end = max(head_end, L - W + 1);
+                for (; i < head_end; ++i) {
+                    double x = xn;
+                    if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                    dtw_row<W, true, FMA>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
+                }
+                for (; i < body_end; ++i) {
+                    double x = xn;
+                    if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                    dtw_row<W, false, FMA>(r, x, y + i, p2, 0, 0, 0);
+                }
+                for (; i < L; ++i) {
+                    double x = xn;
+                    if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                    dtw_row<W, true, FMA>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
+                }
             } else {
-                xn = xp[(int64_t)(W - 1) * ldA];
+                for (; i < L; ++i) {
+                    double x = xn;
+                    if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
+                    dtw_row<W, true, FMA>(r, x, y + i, p2, i - (W - 1), max(0, i - (w - 1)),
+                                          min(L - 1, i + (w - 1)));
+                }
             }
-            for (; i < L - W + 1; ++i) {
-                const double x = xn;
-                xn = xp[(int64_t)(i + 1) * ldA];  // i + 1 <= L - W + 1 < L
-                dtw_row<W, false>(r, x, y + i, p2, 0, 0, 0);
-            }
-            dtw_tail_rows<W>(r, xp, ldA, y, p2, L - W + 1, std::make_integer_sequence<int, W - 1>{});
-        } else if (EXACT_W) {
-            const int head_end = min(W - 1, L);          // rows whose band leaves [0, L)
-            const int body_end = max(head_end, L - W + 1);
-            for (; i < head_end; ++i) {
-                double x = xn;
-                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
-                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
-            }
-            for (; i < body_end; ++i) {
-                double x = xn;
-                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
-                dtw_row<W, false>(r, x, y + i, p2, 0, 0, 0);
-            }
-            for (; i < L; ++i) {
-                double x = xn;
-                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
-                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), 0, L - 1);
-            }
-        } else {
-            for (; i < L; ++i) {
-                double x = xn;
-                if (i + 1 < L) xn = xp[(int64_t)(i + 1) * ldA];
-                dtw_row<W, true>(r, x, y + i, p2, i - (W - 1), max(0, i - (w - 1)),
-                                 min(L - 1, i + (w - 1)));
-            }
+            return r[W - 1];
+        };
+        const bool pnan = anan || (b_nan && b_nan[b]);
+        double res;
+        bool redo = unfused == 1;   // (uniform)
+        if (!redo) {
+            const double Dv = pair_cost(std::true_type{});
+            res = sqrt(Dv);
+            redo = dtw_redo(unfused, !pnan && dtw_unsettled(Dv, res, (float)res, delta));   // (the wave's decision)
         }
-        double res = sqrt(r[W - 1]);
-        if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
+        if (redo) res = sqrt(pair_cost(std::false_type{}));
+        if (pnan) res = __builtin_nan("");
         float f = (float)res;
         if (active) out[a * sA + (int64_t)b * sB] = f;
         acc.push(f, b);
@@ -230,7 +277,7 @@ __global__ __launch_bounds__(64) void dtw_band_kernel(
 // are computed (515 of the 725 that the rolling-band kernel evaluates for L = 25, all of them with
 // masks there).  Same float64 operations per cell as dtw_row -> identical bits.
 // row I of the short-series DP; everything about the band is a compile-time constant
-template <int L, int W, int I>
+template <int L, int W, int I, bool FMA>
 __device__ __forceinline__ void dtw_short_row(double (&D)[L], const double xi, const double *__restrict__ y,
                                               const double p2) {
     constexpr int jlo = I - (W - 1) > 0 ? I - (W - 1) : 0;
@@ -240,22 +287,44 @@ __device__ __forceinline__ void dtw_short_row(double (&D)[L], const double xi, c
 #pragma unroll
     for (int j = jlo; j <= jhi; ++j) {
         const double up = D[j];
-        double d = xi - y[j];
-        d = d * d;
+        const double d = xi - y[j];
         // min(min(up, left) + p2, diag) == min(min(up + p2, diag), left + p2) (rounding is monotone): the part that
         // does not depend on the cell to the left is off the row's dependency chain (3 dependent ops per cell, not 4)
         double t = __builtin_fmin(up + p2, diag);
         if (j != jlo) t = __builtin_fmin(t, left + p2);
-        const double v = d + t;
+        const double v = dtw_cell<FMA>(d, t);
         diag = up;
         D[j] = v;
         left = v;
     }
 }
-template <int L, int W, int... Is>
+template <int L, int W, bool FMA, int... Is>
 __device__ __forceinline__ void dtw_short_rows(double (&D)[L], const double (&x)[L], const double *__restrict__ y,
                                                const double p2, std::integer_sequence<int, Is...>) {
-    (dtw_short_row<L, W, Is>(D, x[Is], y, p2), ...);
+    (dtw_short_row<L, W, Is, FMA>(D, x[Is], y, p2), ...);
+}
+// the pair's distance as float64, the reference's float32 after conversion (see dtw_unsettled)
+template <int L, int W>
+__device__ __forceinline__ double dtw_short_pair(const double (&x)[L], const double *__restrict__ y, const double p2,
+                                                 const bool pnan, const double delta, const int unfused) {
+    double res;
+    bool redo = unfused == 1;   // (uniform)
+    if (!redo) {
+        double D[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
+        dtw_short_rows<L, W, true>(D, x, y, p2, std::make_integer_sequence<int, L>{});
+        res = sqrt(D[L - 1]);
+        redo = dtw_redo(unfused, !pnan && dtw_unsettled(D[L - 1], res, (float)res, delta));
+    }
+    if (redo) {
+        double D[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
+        dtw_short_rows<L, W, false>(D, x, y, p2, std::make_integer_sequence<int, L>{});
+        res = sqrt(D[L - 1]);
+    }
+    return pnan ? __builtin_nan("") : res;
 }
 
 template <int L, int W, bool ROWMAJOR>
@@ -263,12 +332,13 @@ __global__ __launch_bounds__(64) void dtw_short_kernel(
     const double *__restrict__ AT, int64_t ldA, int64_t nA, const uint8_t *__restrict__ a_nan,
     const double *__restrict__ Bpad, int64_t Lpad, int halo, int nB,
     const uint8_t *__restrict__ b_nan, double p2, float *__restrict__ out, int64_t sA, int64_t sB,
-    int32_t *__restrict__ argmin, int refs_per_block) {
+    int32_t *__restrict__ argmin, int refs_per_block, int unfused) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = a < nA;
     const int64_t al = active ? a : nA - 1;
     const int b0 = blockIdx.y * refs_per_block;
     const int b1 = min(nB, b0 + refs_per_block);
+    const double delta = dtw_delta(L);
     double x[L];
     bool anan = a_nan ? (a_nan[al] != 0) : false;
 #pragma unroll
@@ -280,12 +350,7 @@ __global__ __launch_bounds__(64) void dtw_short_kernel(
     ArgminAcc acc;
     for (int b = b0; b < b1; ++b) {
         const double *__restrict__ y = Bpad + (int64_t)b * Lpad + halo;
-        double D[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
-        dtw_short_rows<L, W>(D, x, y, p2, std::make_integer_sequence<int, L>{});
-        double res = sqrt(D[L - 1]);
-        if (anan || (b_nan && b_nan[b])) res = __builtin_nan("");
+        const double res = dtw_short_pair<L, W>(x, y, p2, anan || (b_nan && b_nan[b]), delta, unfused);
         const float f = (float)res;
         if (active) out[a * sA + (int64_t)b * sB] = f;
         acc.push(f, b);
@@ -520,10 +585,10 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
     if (L == 25 && w == 15 && !knobs.no_short_dtw) {
         if (a_rowmajor)
             hipLaunchKernelGGL((dtw_short_kernel<25, 15, true>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad,
-                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
+                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb, knobs.dtw_unfused);
         else
             hipLaunchKernelGGL((dtw_short_kernel<25, 15, false>), grid, dim3(64), 0, stream, AT, ldA, nA, a_nan, Bpad,
-                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb);
+                               Lpad, halo, (int)nB, b_nan, p2, out, sA, sB, fused_argmin, rpb, knobs.dtw_unfused);
         WDX_HIP_TRY(hipGetLastError());
         if (d_argmin && !fused_argmin) return launch_argmin(out, nA, nB, d_argmin, stream);
         return WDX_SUCCESS;
@@ -533,11 +598,11 @@ int launch_dtw(const double *AT, int64_t ldA, int64_t nA, const uint8_t *a_nan, 
         if (a_rowmajor)                                                                                  \
             hipLaunchKernelGGL((dtw_band_kernel<WW, EX, true>), grid, dim3(64), 0, stream, AT, ldA, nA,  \
                                a_nan, Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB,      \
-                               fused_argmin, rpb);                                                       \
+                               fused_argmin, rpb, knobs.dtw_unfused);                                    \
         else                                                                                             \
             hipLaunchKernelGGL((dtw_band_kernel<WW, EX, false>), grid, dim3(64), 0, stream, AT, ldA, nA, \
                                a_nan, Bpad, Lpad, halo, (int)nB, b_nan, (int)L, w, p2, out, sA, sB,      \
-                               fused_argmin, rpb);                                                       \
+                               fused_argmin, rpb, knobs.dtw_unfused);                                    \
     } while (0)
     if (w == 15) {
         WDX_LAUNCH_BAND(15, true);
@@ -577,6 +642,7 @@ struct DtwSvmArgs {
     int km1, pwr;
     float ngamma;
     double *P;                  // [n_slots][k - 1][nA]
+    int unfused;                // 1: the reference's six operations per cell only (WDX_OPT_DTW_UNFUSED)
 };
 template <int L, int W>
 __global__ __launch_bounds__(64, 3) void dtw_short_svm_kernel(DtwSvmArgs G) {
@@ -587,6 +653,7 @@ __global__ __launch_bounds__(64, 3) void dtw_short_svm_kernel(DtwSvmArgs G) {
     const int64_t al = active ? a : G.nA - 1;
     const int b0 = G.chunk_ref0[blockIdx.y], b1 = G.chunk_ref0[blockIdx.y + 1];
     const int km1 = G.km1;
+    const double delta = dtw_delta(L);
     double x[L];
     bool anan = false;
 #pragma unroll
@@ -597,12 +664,7 @@ __global__ __launch_bounds__(64, 3) void dtw_short_svm_kernel(DtwSvmArgs G) {
     for (int q = 0; q < km1; ++q) sums[q][lane] = 0.0;
     for (int b = b0; b < b1; ++b) {
         const double *__restrict__ y = G.Ypad + (int64_t)b * G.Lpad + G.halo;
-        double D[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) D[j] = WDX_INF;
-        dtw_short_rows<L, W>(D, x, y, G.p2, std::make_integer_sequence<int, L>{});
-        double res = sqrt(D[L - 1]);
-        if (anan || (G.y_nan && G.y_nan[b])) res = __builtin_nan("");
+        const double res = dtw_short_pair<L, W>(x, y, G.p2, anan || (G.y_nan && G.y_nan[b]), delta, G.unfused);
         const float d = (float)res;   // the float32 distance distance_matrix_to returns (parallel_distances.py:59-67)
         const float t = G.pwr == 1 ? d : (G.pwr == 2 ? d * d : powf(d, (float)G.pwr));
         const double kv = (double)expf(G.ngamma * t);
@@ -618,13 +680,13 @@ __global__ __launch_bounds__(64, 3) void dtw_short_svm_kernel(DtwSvmArgs G) {
 int launch_dtw_svm_partial(const double *X, int64_t nA, const double *Ypad_sv, int64_t Lpad, int halo, const uint8_t *y_nan_sv,
                            int64_t L, int window, double penalty, const double *coefT, const int32_t *chunk_ref0,
                            const int32_t *chunk_slot, int n_chunks, int km1, int pwr, float ngamma, double *P,
-                           hipStream_t stream) {
+                           hipStream_t stream, int unfused) {
     if (nA == 0 || n_chunks == 0) return WDX_SUCCESS;
     if (L != 25 || window != 15 || km1 < 1 || km1 > 15) {
         set_error("the fused DTW + SVM path serves the shipped shape (25-point fingerprints, window 15, <= 16 classes)");
         return WDX_ERR_UNSUPPORTED;
     }
-    DtwSvmArgs G{X, nA, Ypad_sv, Lpad, halo, y_nan_sv, penalty * penalty, coefT, chunk_ref0, chunk_slot, km1, pwr, ngamma, P};
+    DtwSvmArgs G{X, nA, Ypad_sv, Lpad, halo, y_nan_sv, penalty * penalty, coefT, chunk_ref0, chunk_slot, km1, pwr, ngamma, P, unfused};
     dim3 grid((unsigned)((nA + 63) / 64), (unsigned)n_chunks);
     hipLaunchKernelGGL((dtw_short_svm_kernel<25, 15>), grid, dim3(64), 0, stream, G);
     WDX_HIP_TRY(hipGetLastError());
