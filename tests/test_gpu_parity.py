@@ -152,9 +152,9 @@ def _dtw_mode(mode):
 
 def test_dtw_fused_cells_settle_to_the_reference_bits():
     """The DTW kernels compute a cell as one v_fma_f64 (five float64 operations, not six) and run a pair again on the
-    reference's operations whenever its float32 could differ (wdx_dtw.hip: dtw_unsettled).  Fixture g10: the 11 pairs of
-    4.6e10 searched on an MI355X whose fused float32 DOES differ (tools/find_fused_hard_pairs.py; inputs only, the
-    expected distances are the oracle's, computed here).  On them, and on everything around them: the product mode, the
+    reference's operations whenever its float32 could differ (wdx_dtw.hip: dtw_unsettled).  Fixture g10: 64 of the 248
+    pairs among 9.1e11 searched on an MI355X whose fused float32 DOES differ (tools/find_fused_hard_pairs.py,
+    profiles/r06d_fused_pair_search.txt; inputs only, the expected distances are the oracle's, computed here).  On them, and on everything around them: the product mode, the
     six-operations mode and the settle-everything mode return the oracle's bits; the never-settle diagnostic does not
     (the positive control: these pairs are what the check exists for).  Scaled inputs reach the underflow / overflow
     guards of the check."""
@@ -177,7 +177,7 @@ def test_dtw_fused_cells_settle_to_the_reference_bits():
         with _dtw_mode(3):
             raw = pdist.distance_matrix_to(X, y, window=w, penalty=p, n_jobs=1)
         assert all(raw[at[i], i] != ref[at[i], i] for i in range(m)), "the fixture's pairs no longer tell fused from unfused cells"
-        assert np.count_nonzero(raw != ref) == m
+        assert m <= np.count_nonzero(raw != ref) <= 2 * m   # (a query that is hard against two references sits in the fixture twice)
         assert np.allclose(raw, ref, rtol=2e-7, atol=0.0)   # (one float32 ulp)
     # the guards: sums below 1e-280 / above 1e280 are settled on the reference's operations (underflow makes errors absolute)
     rng = np.random.default_rng(2)

@@ -3,8 +3,9 @@ WDX_OPT_DTW_UNFUSED = 3) and the reference's six operations (= 1): about two pai
 return the reference's float32 on them -- they are what wdx_dtw.hip's dtw_unsettled() exists for.  Needs an MI355X; writes
 gpurun_out/g10_dtw_fused_hard_pairs.npz {x25, y25, x110, y110, window, penalty, pairs_searched} (committed as
 tests/golden/g10_dtw_fused_hard_pairs.npz) -- inputs only: the expected values are computed by the oracle when the test
-runs (tests/test_gpu_parity.py::test_dtw_fused_cells_settle_to_the_reference_bits).  Round 6: 10 pairs of 4.2e10 at
-L = 25, 1 of 4.1e9 at L = 110; the default mode returned the reference's float32 on every pair searched.
+runs (tests/test_gpu_parity.py::test_dtw_fused_cells_settle_to_the_reference_bits).  Round 6, 160 rounds: 224 pairs of
+8.3e11 at L = 25, 24 of 8.2e10 at L = 110 (profiles/r06d_fused_pair_search.txt; the fixture keeps the first 40 and all
+24); the default mode returned the reference's float32 on every pair searched.
 Usage: python3 tools/find_fused_hard_pairs.py [rounds]"""
 import os
 import sys
