@@ -27,6 +27,15 @@ def test_header_symbols_are_exported():
     assert L.wdx_abi_version() == _lib.ABI_VERSION == 4
 
 
+def test_option_and_kernel_constants_match_the_header():
+    """every WDX_OPT_* / WDX_K_* / WDX_WANT_* the header defines has the same value in the ctypes layer (and vice versa)"""
+    hdr = open(os.path.join(ROOT, "include", "wdx.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+WDX_((?:OPT|K|WANT)_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", hdr, flags=re.M)}
+    assert defs["OPT_DTW_UNFUSED"] == 16 and defs["OPT_NO_SPLIT_TAIL"] == 15
+    mine = {k: getattr(_lib, k) for k in dir(_lib) if re.match(r"(OPT|K|WANT)_[A-Z0-9_]+$", k)}
+    assert mine == defs, {k: (mine.get(k), defs.get(k)) for k in set(mine) ^ set(defs) | {k for k in mine if k in defs and mine[k] != defs[k]}}
+
+
 def test_seg_params_struct_layout_matches_header():
     hdr = open(os.path.join(ROOT, "include", "wdx.h")).read()
     body = hdr[hdr.index("typedef struct wdx_seg_params {"): hdr.index("} wdx_seg_params;")]

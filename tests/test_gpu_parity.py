@@ -196,6 +196,39 @@ def test_dtw_fused_cells_settle_to_the_reference_bits():
                 _check_dist(pdist.distance_matrix_to(X, Y, window=wv, penalty=0.1, n_jobs=1), ref)
 
 
+def test_dtw_fused_and_six_operation_forms_agree_at_the_headline_size():
+    """BASELINE's C3 shape at full size without the oracle: 5 M device-resident 110-point fingerprints x 10 references
+    (one launch of the headline run) and 100 000 x 2 601 x 25 points (the shipped models' shape) -- the product mode must
+    return the six-operation form's float32 and argmin everywhere (the six-operation form IS the oracle's arithmetic:
+    every other DTW test), on random and on near-reference queries."""
+    import torch
+    from warpdemux_amd.engine import DemuxEngine
+    for L, nY, n in ((110, 10, 5_000_000), (25, 2601, 100_000)):
+        rng = np.random.default_rng(L)
+        Y = rng.normal(size=(nY, L))
+        eng = DemuxEngine(Y, 15, 0.1, sig_proc.SegParams(barcode_num_events=L))
+        Yd = torch.from_numpy(Y).to(eng.tdev)
+        for near in (False, True):
+            g = torch.Generator(device=eng.tdev)
+            g.manual_seed(7 * L + int(near))
+            X = torch.randn((n, L), dtype=torch.float64, device=eng.tdev, generator=g)
+            if near:
+                X = Yd[torch.randint(0, nY, (n,), device=eng.tdev, generator=g)] + 0.7 * X
+            out = {}
+            for mode in (1, 0):
+                eng.ctx.set_option(_lib.OPT_DTW_UNFUSED, mode)
+                try:
+                    out[mode] = eng.dtw(X, want_argmin=True)
+                finally:
+                    eng.ctx.set_option(_lib.OPT_DTW_UNFUSED, 0)
+            assert bool(torch.equal(out[0][0], out[1][0])), int((out[0][0] != out[1][0]).sum())
+            assert bool(torch.equal(out[0][1], out[1][1]))
+            assert bool(torch.isfinite(out[0][0]).all())
+            del out, X
+        del eng
+        torch.cuda.empty_cache()
+
+
 def test_dtw_symmetry_and_block_api():
     rng = np.random.default_rng(8)
     X = rng.normal(size=(150, 25))
