@@ -31,7 +31,9 @@ namespace wdx {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kClipWaves = 4;                       // reads per workgroup
+// (one read = one wave = one workgroup: with four reads per workgroup a finished wave's registers and LDS waited for the slowest
+// of the four -- reads differ by their > 64-member levels -- and the kernel ran 45.1 instead of 38.9 ms per 10 M reads)
+constexpr int kClipWaves = 1;                       // reads per workgroup
 constexpr int kClipWaveWords = kHB + 64;            // histogram | member list
 
 struct ClipArgs {
@@ -500,7 +502,7 @@ __device__ __forceinline__ void clip_wave(const FpArgs &A, ClipRec *recs, const 
 }
 
 // workgroups per CU the register budget admits (512 VGPRs per SIMD lane, NPL of them are the samples)
-constexpr int clip_wgs_per_cu(int npl) { return npl <= 80 ? 4 : (npl <= 128 ? 3 : 2); }
+constexpr int clip_wgs_per_cu(int npl) { return (npl <= 80 ? 4 : (npl <= 128 ? 3 : 2)) * (4 / kClipWaves); }
 
 template <int NPL>
 __global__ __launch_bounds__(kClipWaves * 64, clip_wgs_per_cu(NPL)) void clip_bounds_kernel(ClipArgs C) {
