@@ -7,7 +7,7 @@
 //
 // One wave owns one read and keeps ALL its samples in registers (NPL per lane: the 18 KB are read from HBM once more
 // -- the chain used 9 % of the HBM rate -- and never touch LDS); LDS holds only the wave's 2048-bin histogram (8.5 KB
-// per wave, four waves = four independent reads per workgroup).  There is no barrier anywhere: what one lane writes
+// per wave; one wave = one read = one workgroup, see kClipWaves).  There is no barrier anywhere: what one lane writes
 // to LDS the others read in program order (DS operations of a wave execute in issue order).
 //   * extremes of the raw bit patterns (non-negative samples: the pattern orders like the value and is the key;
 //     negative samples -- outliers by construction of the statistic -- are clamped to the smallest non-negative one,
