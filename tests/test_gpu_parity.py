@@ -229,6 +229,45 @@ def test_dtw_fused_and_six_operation_forms_agree_at_the_headline_size():
         torch.cuda.empty_cache()
 
 
+def test_dtw_device_rows_with_nan_and_inf_take_the_lazy_sweep():
+    """wdx_dtw_matrix_dev on row-major device fingerprints carries no NaN flags: the band kernel sweeps a wave's rows only
+    when a result is not finite (a NaN sample leaves no finite cell behind it; wdx_dtw.hip).  Rows with a NaN at the first,
+    a middle and the last sample, rows with +inf, -inf and both, in waves with and without clean rows, against the oracle
+    in the product mode, the six-operation mode and the settle-everything mode."""
+    import torch
+    from warpdemux_amd.engine import DemuxEngine
+    rng = np.random.default_rng(41)
+    L, nY, n = 110, 10, 40_000   # (> 16 384 pairs: the band kernel; row-major device input)
+    Y = rng.normal(size=(nY, L))
+    X = rng.normal(size=(n, L))
+    X[5, 0] = np.nan
+    X[64 + 7, 55] = np.nan
+    X[128 + 63, L - 1] = np.nan
+    X[300, 17] = np.inf
+    X[301, 18] = -np.inf
+    X[302, 3], X[302, 90] = np.inf, -np.inf
+    X[303, 3], X[303, 4] = np.inf, np.nan
+    X[1000:1064, 40] = np.nan               # a whole wave of failed reads
+    X[rng.choice(n, 500, replace=False), rng.integers(0, L, 500)] = np.nan
+    eng = DemuxEngine(Y, 15, 0.1, sig_proc.SegParams(barcode_num_events=L))
+    Xd = torch.from_numpy(X).to(eng.tdev)
+    sub = np.unique(np.concatenate([np.arange(0, 2048), rng.choice(n, 3000, replace=False)]))
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = orc.dtw_matrix(X[sub], Y, 15, 0.1)
+    for mode in (0, 1, 2):
+        eng.ctx.set_option(_lib.OPT_DTW_UNFUSED, mode)
+        try:
+            d, am = eng.dtw(Xd, want_argmin=True)
+        finally:
+            eng.ctx.set_option(_lib.OPT_DTW_UNFUSED, 0)
+        d, am = d.cpu().numpy(), am.cpu().numpy()
+        _check_dist(d[sub], ref)
+        assert np.array_equal(am[sub], orc.argmin_rows(ref))
+        assert np.isnan(d[5]).all() and np.isnan(d[1000:1064]).all() and np.isinf(d[300]).all() and np.isinf(d[301]).all()
+        nanrow = np.isnan(X).any(axis=1)
+        assert np.array_equal(np.isnan(d).any(axis=1), nanrow) and np.array_equal(np.isnan(d).all(axis=1), nanrow)
+
+
 def test_dtw_symmetry_and_block_api():
     rng = np.random.default_rng(8)
     X = rng.normal(size=(150, 25))
