@@ -1763,6 +1763,11 @@ int launch_fingerprint(const float *d_sig, const int64_t *d_row_off, const int32
     FpArgs A{d_sig, d_row_off, d_row_len, stride, n_reads, d_a_start, d_a_end, d_ok,
              p,     d_fpt,     d_dwell,   d_stats, d_status, cap, 0, d_prof, prof_reads, stop_phase, 1, RefineDev{},
              d_big, with_huge ? 1 : 0, knobs.exact_no_list ? 1 : 0};
+    {
+        const uint64_t e1 = (uint64_t)(p.num_events > 0 ? p.num_events : 1);
+        A.e_magic1 = (unsigned)std::min<uint64_t>(((1ull << 32) + e1 - 1) / e1, 0xffffffffull);   // (E = 1: 2^32 - 1 -> q = n - 1, rounded up to n)
+        A.e_magic2 = (unsigned)(((1ull << 32) + 2 * e1 - 1) / (2 * e1));
+    }
     if (rf) {
         if (!rf->query || rf->nq < 1 || rf->nq > kRefineMaxQuery || p.num_events + 1 > kRefineMaxSeries) {
             set_error("consensus refinement: the query must have 1..%d points and num_events + 1 <= %d", kRefineMaxQuery,

@@ -72,7 +72,20 @@ struct FpArgs {
     int peak_filter;     // fast kernels on approximate keys: 1 = drop peaks below kPeakTau at the append (WDX_OPT_NO_PEAK_FILTER)
     unsigned *dbg_reasons;  // WDX_OPT_DEBUG_OCCUPANCY: 16 counters, why the fast kernels handed reads to the exact kernel (else null)
     const ClipRec *clip; // exact kernel behind the launch chain: the reads' clip records (CLIP_OK -> the two medians are not redone); nullable
+    unsigned e_magic1, e_magic2;   // ceil(2^32 / E), ceil(2^32 / 2E) (launch_fingerprint): the fast kernels' window parameters without a division
 };
+
+// (int)rint((double)n / (double)den) -- the reference's `round(n / den)` (sig_proc.py:526-533; banker's rounding) -- in integer
+// arithmetic: magic = ceil(2^32 / den) gives the exact quotient for n * den < 2^32 (n <= 16 384 samples, den <= 2 * 253), and the
+// double quotient can only differ from the rational one's rounding within 2^-53 of a tie, which is exact or >= 1 / (2 den) away.
+// n is uniform: scalar instructions (s_mul_hi_u32) instead of a float64 division expanded on the vector ALU by every lane
+// (checked against the float form for every den <= 506, n < 20 000).
+__device__ __forceinline__ int rdiv_half_even(unsigned n, unsigned den, unsigned magic) {
+    unsigned q = __umulhi(n, magic);
+    const unsigned rem2 = 2u * (n - q * den);
+    q += (rem2 > den || (rem2 == den && (q & 1u))) ? 1u : 0u;
+    return (int)q;
+}
 
 // Clip bounds of one read, computed ahead of the fast kernels' launch chain by clip_bounds_kernel (one wave per read,
 // wdx_fingerprint_clip.inc).  flag: CLIP_NONE = not computed (failed detection, window outside the kernel's range),
